@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py - denoise-steps/sec of the GEN3C-Cosmos-7B DiT on MI355X (BASELINE.json metric).
+
+One "step" = one EDM-Euler denoise step of `DiffusionV2WModel.generate_samples_from_batch` (model_v2w.py:130-149):
+build the network input, net(cond), net(uncond), CFG, conditioning-frame replacement, Euler update - on the
+121x704x1280 video latent [1,16,16,88,160] (56 320 tokens), random-init Cosmos-7B weights (28 blocks x 4096, 32 heads),
+synthetic conditions of SURVEY.md 8d. Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU,
+                                                            context parallel over the 16 latent frames via RCCL)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak per MI355X (/opt/skills/guides/MI355X_MICROARCH.md:42)
+
+
+def dit_forward_flops(N, D=4096, M=512, Dctx=1024, L=28, patch_dim=328, out_dim=64):
+    """L*(28 N D^2 + 4 N^2 D + 4 N M D + 4 M Dctx D) + 2 N patch D + 2 N D out."""
+    return L * (28 * N * D * D + 4 * N * N * D + 4 * N * M * D + 4 * M * Dctx * D) + 2 * N * patch_dim * D + 2 * N * D * out_dim
+
+
+def cpu_baseline(threads: int):
+    """Oracle ('port') timed on the host cores on a bounded sample: ONE Cosmos-7B-width block (D=4096, 32 heads,
+    MLP 16384, context 512x1024) on a 4 096-token latent [16,4,64,64], fp32, 2 repetitions, extrapolated by FLOPs to the
+    full step (the full-size CPU step would take ~3 h)."""
+    from oracle import dit_oracle
+    torch.set_num_threads(threads)
+    D, H, T, Hh, Ww, M = 4096, 32, 4, 64, 64, 512
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    def W(*s, scale=0.02):
+        return torch.randn(*s, generator=g) * scale
+    sd["x_embedder.proj.1.weight"] = W(D, 328)
+    sd["pos_embedder.seq"] = torch.arange(128, dtype=torch.float)
+    for a, n in (("t", 128), ("h", 120), ("w", 120)):
+        sd[f"extra_pos_embedder.pos_emb_{a}"] = W(n, D)
+    sd["t_embedder.1.linear_1.weight"] = W(D, D)
+    sd["t_embedder.1.linear_2.weight"] = W(3 * D, D)
+    pre = "blocks.block0.blocks"
+    for j, cd in ((0, D), (1, 1024)):
+        a = f"{pre}.{j}.block.attn"
+        sd[f"{a}.to_q.0.weight"] = W(D, D); sd[f"{a}.to_q.1.weight"] = torch.ones(128)
+        sd[f"{a}.to_k.0.weight"] = W(D, cd); sd[f"{a}.to_k.1.weight"] = torch.ones(128)
+        sd[f"{a}.to_v.0.weight"] = W(D, cd); sd[f"{a}.to_out.0.weight"] = W(D, D)
+    sd[f"{pre}.2.block.layer1.weight"] = W(4 * D, D); sd[f"{pre}.2.block.layer2.weight"] = W(D, 4 * D)
+    for j in range(3):
+        sd[f"{pre}.{j}.adaLN_modulation.1.weight"] = W(256, D); sd[f"{pre}.{j}.adaLN_modulation.2.weight"] = W(3 * D, 256)
+    sd["final_layer.linear.weight"] = W(64, D)
+    sd["final_layer.adaLN_modulation.1.weight"] = W(256, D); sd["final_layer.adaLN_modulation.2.weight"] = W(2 * D, 256)
+    sd["affline_norm.weight"] = torch.ones(D)
+    x = torch.randn(1, 16, T, Hh, Ww, generator=g)
+    pose = torch.randn(1, 64, T, Hh, Ww, generator=g)
+    mask = torch.zeros(1, 1, T, Hh, Ww)
+    ctx = torch.randn(1, M, 1024, generator=g) * 0.2
+    N = T * (Hh // 2) * (Ww // 2)
+    reps = 2
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(reps):
+            dit_oracle.dit_forward(sd, x, torch.tensor([0.3]), ctx, mask, pose, torch.zeros(1, 1, 8 * Hh, 8 * Ww),
+                                   torch.tensor([24.0]), num_blocks=1, num_heads=H)
+    dt = time.perf_counter() - t0
+    flops = reps * dit_forward_flops(N, L=1)
+    rate = flops / dt
+    step_flops = 2 * dit_forward_flops(56320)
+    return dict(value=rate / step_flops, unit="denoise-steps/sec", cores=threads, kind="port",
+                sample=f"oracle/dit_oracle.py fp32, 1 of 28 blocks (D=4096,H=32) on {N} tokens x{reps}: {dt:.1f}s = {rate/1e12:.3f} TFLOP/s, "
+                       f"extrapolated by FLOPs to the 4.419 PFLOP step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=28, help="(debug only) number of DiT blocks; anything but 28 is not the benchmark")
+    ap.add_argument("--latent", type=str, default="16,88,160", help="(debug only) latent T,H,W")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gen3c_amd import ops
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    from gen3c_amd.parallel import init_distributed, parallel_state
+    from gen3c_amd.sampler import Gen3CDenoiser, VideoExtendCondition, add_condition_video_indicator_and_video_input_mask
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        local = init_distributed("nccl")
+        parallel_state.initialize_model_parallel(context_parallel_size=world)
+    else:
+        local = 0
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local}")
+
+    T, Hl, Wl = (int(v) for v in args.latent.split(","))
+    net = VideoExtendGeneralDIT(in_channels=16 + 16 * 4 + 1, rope_t_extrapolation_ratio=2.0, num_blocks=args.blocks,
+                                device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=1234)  # same weights on every rank
+    if world > 1:
+        net.enable_context_parallel(parallel_state.get_context_parallel_group())
+
+    # ---- synthetic inputs, identical on every rank (host RNG), resident in HBM before timing
+    rs = np.random.RandomState(1)
+    def normal(shape, std):
+        return torch.from_numpy((rs.standard_normal(shape) * std).astype(np.float32)).to(torch.bfloat16).to(dev)
+    B = 1
+    den = Gen3CDenoiser(net, state_shape=(16, T, Hl, Wl))
+    den.scheduler.set_timesteps(35)
+    xt_full = normal((B, 16, T, Hl, Wl), den.scheduler.init_noise_sigma)
+    gt = normal((B, 16, T, Hl, Wl), 0.5)
+    pose = normal((B, 64, T, Hl, Wl), 0.5)
+    ctx = normal((B, 512, 1024), 0.2)
+    ctx[:, 64:] = 0
+    pad = torch.zeros(B, 1, 8 * Hl, 8 * Wl, device=dev, dtype=torch.bfloat16)
+    fps = torch.tensor([24.0], device=dev)
+
+    def make_cond(p):
+        c = VideoExtendCondition(crossattn_emb=ctx, crossattn_mask=None, padding_mask=pad, fps=fps, video_cond_bool=True,
+                                 condition_video_pose=p)
+        return add_condition_video_indicator_and_video_input_mask(gt, c, 1)
+
+    cond, uncond = make_cond(pose), make_cond(torch.zeros_like(pose))
+    from gen3c_amd.parallel import split_inputs_cp
+    xt = split_inputs_cp(xt_full, 2, net.cp_group) if world > 1 else xt_full
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step_id = 0
+    for _ in range(args.warmup):
+        xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
+        step_id += 1
+    barrier()
+    ops.enable_kernel_timers(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
+        step_id += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers = ops.collected_kernel_timers()
+    ops.enable_kernel_timers(False)
+    finite = bool(torch.isfinite(xt.float()).all())
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # ---- dominant kernel: self-attention flash-attention forward, timed live with hipEvents on its launch stream
+    N_tok = T * (Hl // 2) * (Wl // 2)
+    self_attn = [(meta, tm.elapsed_ms()) for (name, meta, tm) in timers if name == "flash_attn_fwd" and meta["Skv"] >= N_tok // max(world, 1) and meta["Skv"] > 512]
+    roof = None
+    if self_attn:
+        avg_ms = sum(ms for _, ms in self_attn) / len(self_attn)
+        flops_launch = sum(4.0 * m["Sq"] * m["Skv"] * m["H"] * 128 * m["B"] for m, _ in self_attn) / len(self_attn)
+        ach = flops_launch / (avg_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="flash_attn_fwd_kernel", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
+                    flops_per_launch=flops_launch)
+
+    if rank == 0:
+        step_flops = 2 * dit_forward_flops(N_tok, L=args.blocks)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = args.steps / elapsed
+        out = {
+            "metric": "denoise-steps/sec (121x1280x704 latent, Cosmos-7B)", "value": round(value, 5), "unit": "denoise-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"GEN3C-Cosmos-7B denoise step: 2 DiT forwards (cond+uncond) + CFG + latent replace + Euler on latent "
+                                   f"[1,16,{T},{Hl},{Wl}] = {N_tok} tokens, {args.blocks} blocks x 4096, 32 heads, guidance=1, 35-step Karras schedule, "
+                                   f"random-init weights", "parallelism": f"cp{world}" if world > 1 else "single-gpu",
+                       "step_pflop": round(step_flops / 1e15, 4)},
+            "step_tflops_per_gpu": round(step_flops / (elapsed / args.steps) / 1e12 / world, 1),
+            "step_mfma_frac": round(step_flops / (elapsed / args.steps) / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+            "output_finite": finite,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(threads=os.cpu_count() or 1)
+            except Exception as e:  # the baseline must never hide the measurement
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+// Error plumbing + version for the C ABI declared in include/gen3c_hip.h.
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int g3_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int g3_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return G3_OK;
+}
+
+extern "C" const char* g3_last_error(void) { return g_err; }
+extern "C" int g3_abi_version(void) { return 1; }
+
+// Device facts the host side uses to size grids (CU count) and to refuse running on anything but gfx950.
+extern "C" int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name, int arch_name_len) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_device_info: %s", hipGetErrorString(e));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (is_gfx950) *is_gfx950 = (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+    if (arch_name && arch_name_len > 0) snprintf(arch_name, arch_name_len, "%s", prop.gcnArchName);
+    return G3_OK;
+}
+
+// hipEvent helpers so bench.py can time kernels on the exact stream they were launched on without torch types.
+extern "C" int g3_event_create(void** ev) {
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_event_create: %s", hipGetErrorString(r));
+    *ev = (void*)e;
+    return G3_OK;
+}
+extern "C" int g3_event_record(void* ev, void* stream) {
+    hipError_t r = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    if (r != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_event_record: %s", hipGetErrorString(r));
+    return G3_OK;
+}
+extern "C" int g3_event_elapsed_ms(void* start, void* stop, float* ms) {
+    hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+    if (r == hipSuccess) r = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (r != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_event_elapsed_ms: %s", hipGetErrorString(r));
+    return G3_OK;
+}
+extern "C" int g3_event_destroy(void* ev) {
+    (void)hipEventDestroy((hipEvent_t)ev);
+    return G3_OK;
+}

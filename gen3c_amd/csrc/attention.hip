@@ -1,0 +1,244 @@
+// Flash-attention forward (no mask, no dropout, head_dim 128, bf16 in/out, fp32 softmax + accumulation).
+//
+// Replaces TransformerEngine's DotProductAttention as used by the reference DiT
+// (cosmos_predict1/diffusion/module/attention.py:228-238 constructed, :288 called: q,k,v "sbhd",
+// attn_mask_type="no_mask", scale = 1/sqrt(head_dim)) for both self-attention (S_kv = S_q = 56 320 tokens) and
+// cross-attention (S_kv = 512 zero-padded T5 tokens, UNMASKED: general_dit.py:407-410).
+//
+// MI355X-first design:
+//   * workgroup = 8 wave64; each wave owns 32 query rows (block = 256 rows) and all 128 output dims;
+//   * scores are computed TRANSPOSED  S^T[kv][q] = K . Q^T  with v_mfma_f32_32x32x16_bf16, so that one lane owns
+//     one query column: row-max / row-sum are lane-local plus ONE cross-lane exchange (lane ^ 32);
+//   * the K-tile rows are fed to the MFMA with bits 2 and 3 of the row index swapped. With that permutation the
+//     accumulator registers a lane holds after QK^T are, in order, exactly the 8 consecutive kv positions the
+//     lane must supply as B-operand of the PV product - P never leaves registers (no LDS round trip, no permute);
+//   * V is consumed as V^T [head][128][S_kv] (written by g3_transpose_v_bf16 right after the QKV projection), so
+//     the PV A-operand is a plain 16-byte LDS read like K's - no transposing reads;
+//   * O is accumulated transposed (O^T[d][q]): the online-softmax rescale is a lane-local scalar multiply;
+//   * K tile [64][128] is XOR-swizzled by (row & 15), V^T tile [128][64] by ((row>>1) & 7): every ds_read_b128
+//     lane group covers all 64 banks (conflict-free);
+//   * split staging (global->reg before the MFMAs, reg->LDS after) double-buffered, one barrier per KV tile;
+//   * softmax in the exp2 domain; the 1/sqrt(d)*log2(e) factor is applied in fp32 AFTER the MFMA (no extra
+//     bf16 rounding of Q);
+//   * grid = (q_blocks, heads, batch): consecutive workgroups share a head, so all 8 XCD L2s stream the same
+//     K/V^T panels.
+#include "common.hpp"
+
+namespace {
+
+constexpr int HD = 128;      // head dim
+constexpr int QB = 32;       // q rows per wave
+constexpr int NWAVES = 8;
+constexpr int BQ = QB * NWAVES;  // 256 q rows per block
+constexpr int KVB = 64;      // kv per tile
+constexpr int NTHREADS = 64 * NWAVES;
+
+struct AttnParams {
+    const bf16_t* Q; int64_t q_row, q_batch, q_head;      // element strides
+    const bf16_t* K; int64_t k_row, k_batch, k_head;
+    const bf16_t* Vt; int64_t vt_row, vt_batch, vt_head;  // V^T[b][h][d][kv]; vt_row = leading dim (>= ceil64(S_kv))
+    bf16_t* O; int64_t o_row, o_batch, o_head;
+    int Sq, Skv;
+    float scale_log2;  // softmax_scale * log2(e)
+};
+
+G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
+G3_DEVICE int v_off(int row, int chunk) { return row * KVB + ((chunk ^ ((row >> 1) & 7)) << 3); }  // [128][64]
+G3_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
+    bf16_t* sV = sK + 2 * KVB * HD;                     // [2][128][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const int head = blockIdx.y;
+    const int batch = blockIdx.z;
+
+    const bf16_t* Qb = p.Q + batch * p.q_batch + head * p.q_head;
+    const bf16_t* Kb = p.K + batch * p.k_batch + head * p.k_head;
+    const bf16_t* Vb = p.Vt + batch * p.vt_batch + head * p.vt_head;
+    bf16_t* Ob = p.O + batch * p.o_batch + head * p.o_head;
+
+    // ---- Q fragments (B operand: column = q row, k = head dim), straight from global memory
+    const int q_idx = blockIdx.x * BQ + wave * QB + l31;
+    const bool q_ok = q_idx < p.Sq;
+    bf16x8 qf[8];
+    {
+        const bf16_t* qrow = Qb + (int64_t)(q_ok ? q_idx : 0) * p.q_row + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = q_ok ? load_bf16x8(qrow + 16 * ks) : zero_bf16x8();
+    }
+
+    // ---- staging assignment (2 K chunks + 2 V^T chunks per thread per tile)
+    bf16x8 rk[2], rv[2];
+    auto stage_load = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            {
+                const int row = idx >> 4, chunk = idx & 15;
+                const bool ok = (kv0 + row) < p.Skv;
+                rk[i] = ok ? load_bf16x8(Kb + (int64_t)(kv0 + row) * p.k_row + chunk * 8) : zero_bf16x8();
+            }
+            {
+                const int row = idx >> 3, chunk = idx & 7;
+                const bool ok = (kv0 + chunk * 8) < p.Skv;  // padding inside a valid chunk is zero-filled by the producer
+                rv[i] = ok ? load_bf16x8(Vb + (int64_t)row * p.vt_row + kv0 + chunk * 8) : zero_bf16x8();
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+        bf16_t* dK = sK + buf * KVB * HD;
+        bf16_t* dV = sV + buf * HD * KVB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            store_bf16x8(dK + k_off(idx >> 4, idx & 15), rk[i]);
+            store_bf16x8(dV + v_off(idx >> 3, idx & 7), rv[i]);
+        }
+    };
+
+    f32x16 accO[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accO[d][r] = 0.f;
+    float m_run = -1e30f;  // running max in the scaled (log2) domain
+    float l_run = 0.f;     // this lane's partial row sum (partner lane^32 holds the rest)
+
+    const int krow_perm = swap23(l31);
+    const int nt = (p.Skv + KVB - 1) / KVB;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const int kv0 = t * KVB;
+        if (t + 1 < nt) stage_load(kv0 + KVB);
+
+        const bf16_t* cK = sK + buf * KVB * HD;
+        const bf16_t* cV = sV + buf * HD * KVB;
+
+        // ---- S^T = K . Q^T   (two 32-kv row blocks)
+        f32x16 accS[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accS[mb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = load_bf16x8(cK + k_off(32 * mb + krow_perm, 2 * ks + g));
+                accS[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[mb], 0, 0, 0);
+            }
+        }
+        // accS[mb][r] belongs to kv = kv0 + 32*mb + 16*(r>>3) + 8*g + (r&7)   (after the bit-2/3 row permutation)
+
+        if (kv0 + KVB > p.Skv) {  // ragged last tile: mask out-of-range keys (wave-uniform branch)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + 32 * mb + 16 * (r >> 3) + 8 * g + (r & 7);
+                    if (kv >= p.Skv) accS[mb][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (one query column per lane)
+        float mx = accS[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, accS[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, accS[1][r]);
+        mx = fmaxf(mx, wave_xor_f32(mx, 32));
+        const float m_new = fmaxf(m_run, mx * p.scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+
+        float psum = 0.f;
+        bf16x8 pb[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(accS[mb][r], p.scale_log2, -m_new));
+                psum += pv;
+                pb[2 * mb + (r >> 3)][r & 7] = f32_to_bf16(pv);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bf16x8 vf = load_bf16x8(cV + v_off(32 * d + l31, 2 * s + g));
+                accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], accO[d], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nt) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise and store. accO[d][r]: dim = 32d + (r&3) + 8*(r>>2) + 4*g ; query = l31
+    const float l_tot = l_run + wave_xor_f32(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(accO[d][4 * q4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * q4 + 4 * g) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k,
+                                      int64_t k_row, int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row,
+                                      int64_t vt_batch, int64_t vt_head, void* o, int64_t o_row, int64_t o_batch,
+                                      int64_t o_head, int Sq, int Skv, int B, int H, int head_dim, float softmax_scale,
+                                      void* stream) {
+    if (!q || !k || !vt || !o) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
+    if (head_dim != HD) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: head_dim %d unsupported (128 only)", head_dim);
+    if (Sq <= 0 || Skv <= 0 || B <= 0 || H <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: bad shape");
+    if ((q_row & 7) || (k_row & 7) || (vt_row & 7) || (o_row & 3) || (q_batch & 7) || (k_batch & 7) || (vt_batch & 7) ||
+        (q_head & 7) || (k_head & 7) || (vt_head & 7) || (o_batch & 3) || (o_head & 3))
+        return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: strides must keep 16-byte (q,k,vt) / 8-byte (o) alignment");
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) || ((uintptr_t)o & 7))
+        return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: misaligned pointer");
+    if (vt_row < ((Skv + 7) & ~7)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: vt leading dim %lld < S_kv rounded to 8", (long long)vt_row);
+    AttnParams p;
+    p.Q = (const bf16_t*)q; p.q_row = q_row; p.q_batch = q_batch; p.q_head = q_head;
+    p.K = (const bf16_t*)k; p.k_row = k_row; p.k_batch = k_batch; p.k_head = k_head;
+    p.Vt = (const bf16_t*)vt; p.vt_row = vt_row; p.vt_batch = vt_batch; p.vt_head = vt_head;
+    p.O = (bf16_t*)o; p.o_row = o_row; p.o_batch = o_batch; p.o_head = o_head;
+    p.Sq = Sq; p.Skv = Skv;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((Sq + BQ - 1) / BQ, H, B);
+    hipLaunchKernelGGL(flash_attn_fwd_kernel, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    return g3_check_launch("g3_flash_attn_fwd_bf16");
+}

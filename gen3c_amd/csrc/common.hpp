@@ -1,0 +1,40 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the GEN3C denoising path.
+// Wave = 64 lanes everywhere. No portability shims: this code only targets gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define G3_DEVICE __device__ __forceinline__
+
+// status codes of the C ABI (include/gen3c_hip.h)
+#define G3_OK 0
+#define G3_ERR_ARG 1
+#define G3_ERR_LAUNCH 2
+
+int g3_set_error(int code, const char* fmt, ...);
+int g3_check_launch(const char* what);
+
+G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }
+G3_DEVICE bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32 on gfx950)
+
+G3_DEVICE bf16x8 load_bf16x8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+G3_DEVICE void store_bf16x8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+G3_DEVICE bf16x8 zero_bf16x8() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, z);
+}
+
+G3_DEVICE float wave_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+G3_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+G3_DEVICE float silu(float x) { return x / (1.0f + __expf(-x)); }

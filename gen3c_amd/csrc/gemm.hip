@@ -1,0 +1,240 @@
+// bf16 "NT" GEMM for the DiT linears:  C[M,N] = epi( A[M,K] . W[N,K]^T )
+//
+// Replaces the nn.Linear(bias=False) calls of the reference's DiT blocks
+// (cosmos_predict1/diffusion/module/attention.py:61-62,207-223; blocks.py:160-162,205-206) together with
+// the elementwise tail each of them feeds (GELU: attention.py:94-99; gated residual: blocks.py:455-471).
+//
+// MI355X design (not a port of any CUDA tiling):
+//   * one workgroup = 8 wave64 = 512 threads computes a 256(token) x 256(feature) tile, K-step 64;
+//   * v_mfma_f32_32x32x16_bf16, operands swapped (A-operand = weight rows, B-operand = token rows) so that a
+//     lane ends up owning 4 CONSECUTIVE output features of one token row -> 8-byte stores, and per-feature
+//     epilogue vectors (gate) are lane-local;
+//   * both operands have K contiguous, so every fragment is one 16-byte LDS read; both MFMA inputs use the
+//     same lane->k mapping, so the contraction is independent of the hardware's k order inside a fragment;
+//   * LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B chunk index XOR-ed by (row>>1)&7, which makes
+//     every 16-lane ds_read_b128 group hit 16 distinct 16-B slots of the 256-B bank row (conflict-free);
+//   * global->register->LDS staging is split (issue the loads for tile t+1 before the MFMAs of tile t, write
+//     them to the other LDS buffer afterwards) so HBM/L2 latency hides under 32 MFMAs per wave; one barrier/tile;
+//   * blockIdx is remapped so that the 8 XCDs each own a contiguous band of token tiles (private L2 reuse of
+//     the weight panel).
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 256;  // tokens per block tile
+constexpr int BN = 256;  // features per block tile
+constexpr int BK = 64;
+constexpr int NTHREADS = 512;
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3 };
+
+struct GemmParams {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    bf16_t* C; int64_t ldc;
+    int M, N, K;
+    const bf16_t* gate; int gate_rows; int64_t ldg;  // gate[(m % gate_rows)][n]  (EPI_GATED_RESIDUAL) / bias (EPI_BIAS)
+    const bf16_t* R; int64_t ldr;                     // residual rows
+    int tiles_m, tiles_n;
+};
+
+G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);  // [2][BM][BK]
+    bf16_t* sW = sA + 2 * BM * BK;                      // [2][BN][BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+
+    // XCD-aware tile order: dispatch puts block b on XCD b%8. Give each XCD a contiguous run of tiles.
+    // tiles are enumerated feature-tile-fastest inside a token tile so neighbours share the A panel in L2.
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + slot;  // bijective for any nblk
+    }
+    const int tile_m = bid / p.tiles_n;
+    const int tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- staging assignment: 4 chunks of A and 4 of W per thread per K tile
+    const int ld_chunk = tid & 7;
+    const int ld_row = tid >> 3;  // + 64*i
+    const bf16_t* a_ptr[4];
+    const bf16_t* w_ptr[4];
+    bool a_ok[4], w_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = ld_row + 64 * i;
+        a_ok[i] = (m0 + row) < p.M;
+        w_ok[i] = (n0 + row) < p.N;
+        a_ptr[i] = p.A + (int64_t)(a_ok[i] ? (m0 + row) : 0) * p.lda + ld_chunk * 8;
+        w_ptr[i] = p.W + (int64_t)(w_ok[i] ? (n0 + row) : 0) * p.ldw + ld_chunk * 8;
+    }
+
+    bf16x8 ra[4], rw[4];
+    auto stage_load = [&](int k0) {
+        const bool k_ok = (k0 + ld_chunk * 8) < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (a_ok[i] && k_ok) ? load_bf16x8(a_ptr[i] + k0) : zero_bf16x8();
+            rw[i] = (w_ok[i] && k_ok) ? load_bf16x8(w_ptr[i] + k0) : zero_bf16x8();
+        }
+    };
+    auto stage_write = [&](int buf) {
+        bf16_t* dA = sA + buf * BM * BK;
+        bf16_t* dW = sW + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = ld_row + 64 * i;
+            store_bf16x8(dA + lds_off(row, ld_chunk), ra[i]);
+            store_bf16x8(dW + lds_off(row, ld_chunk), rw[i]);
+        }
+    };
+
+    // ---- wave tile: 128 features x 64 tokens
+    const int wn = wave & 1;
+    const int wm = wave >> 1;
+    const int n_w0 = wn * 128;
+    const int m_w0 = wm * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) stage_load((t + 1) * BK);
+
+        const bf16_t* cA = sA + buf * BM * BK;
+        const bf16_t* cW = sW + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = 2 * ks + g;
+            bf16x8 wf[4], af[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = load_bf16x8(cW + lds_off(n_w0 + 32 * i + l31, chunk));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[j] = load_bf16x8(cA + lds_off(m_w0 + 32 * j + l31, chunk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+
+        if (t + 1 < nk) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue. acc[i][j][r]: feature = n_w0+32i + (r&3) + 8*(r>>2) + 4*g ; token = m_w0+32j + l31
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + m_w0 + 32 * j + l31;
+        if (m >= p.M) continue;
+        bf16_t* crow = p.C + (int64_t)m * p.ldc;
+        const bf16_t* rrow = (EPI == EPI_GATED_RESIDUAL) ? (p.R + (int64_t)m * p.ldr) : nullptr;
+        const bf16_t* grow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS)
+                                 ? (p.gate + (int64_t)(m % p.gate_rows) * p.ldg)
+                                 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n = n0 + n_w0 + 32 * i + 8 * q4 + 4 * g;
+                if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (EPI == EPI_GATED_RESIDUAL) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
+                    // reference order (blocks.py:456): block output is rounded to bf16 by its Linear, then
+                    // gate*out and x+.. ; we keep fp32 until the single final rounding.
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)rv[e] + (float)gv[e] * v[e];
+                } else if (EPI == EPI_BIAS) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)gv[e];
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
+                *reinterpret_cast<bf16x4*>(crow + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);  // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int nblk = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(nblk), dim3(NTHREADS), smem, stream, p);
+    return g3_check_launch("g3_gemm_bf16_nt");
+}
+
+}  // namespace
+
+extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M,
+                               int N, int K, int epilogue, const void* gate, int gate_rows, int64_t ldg,
+                               const void* residual, int64_t ldr, void* stream) {
+    if (!A || !W || !C) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: null operand");
+    if (M <= 0 || N <= 0 || K <= 0) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    if ((K & 7) || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3))
+        return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: need K,lda,ldw %% 8 == 0 and N,ldc %% 4 == 0 (K=%d lda=%lld ldw=%lld N=%d ldc=%lld)",
+                            K, (long long)lda, (long long)ldw, N, (long long)ldc);
+    if (((uintptr_t)A | (uintptr_t)W) & 15) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: A/W must be 16-byte aligned");
+    if ((uintptr_t)C & 7) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: C must be 8-byte aligned");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = (bf16_t*)C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.gate = (const bf16_t*)gate; p.gate_rows = gate_rows > 0 ? gate_rows : 1; p.ldg = ldg;
+    p.R = (const bf16_t*)residual; p.ldr = ldr;
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case EPI_NONE: return launch<EPI_NONE>(p, s);
+        case EPI_GELU: return launch<EPI_GELU>(p, s);
+        case EPI_GATED_RESIDUAL:
+            if (!gate || !residual || (ldg & 3) || (ldr & 3) || (((uintptr_t)gate | (uintptr_t)residual) & 7))
+                return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: gated-residual epilogue needs 8-byte aligned gate+residual");
+            return launch<EPI_GATED_RESIDUAL>(p, s);
+        case EPI_BIAS:
+            if (!gate || (ldg & 3) || ((uintptr_t)gate & 7)) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: bias epilogue needs bias");
+            return launch<EPI_BIAS>(p, s);
+        default: return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: unknown epilogue %d", epilogue);
+    }
+}

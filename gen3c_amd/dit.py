@@ -1,0 +1,453 @@
+"""MI355X-native stand-in for the reference's `VideoExtendGeneralDIT` (the GEN3C-Cosmos-7B denoiser network).
+
+Boundary (SURVEY.md 8b "Net plugin"): same constructor keywords, same `forward(x, timesteps, crossattn_emb, ...,
+condition_video_pose, **kwargs)` signature and return shape, same `enable_context_parallel / disable_context_parallel /
+is_context_parallel_enabled / cp_group` surface and the SAME state-dict keys as
+cosmos_predict1/diffusion/networks/general_dit_video_conditioned.py:29-217 + general_dit.py:41-569, so the
+`net.*` entries of checkpoints/Gen3C-Cosmos-7B/model.pt load unchanged (TE `*_extra_state` keys are ignored exactly
+like inference_utils.py:240-242 does).
+
+Nothing here computes the network in PyTorch: forward() drives the HIP kernels of libgen3c_hip.so through
+gen3c_amd.ops (GEMM/attention/norm kernels) on torch-allocated HBM buffers. What torch does do is plumbing:
+allocation, the channel concat + patch gather that feeds the embedding GEMM, and building the input-independent
+tables (RoPE cos/sin, normalised absolute position embedding) once per (shape, fps).
+"""
+from __future__ import annotations
+
+import math
+from enum import Enum
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .parallel import ContextParallelAttention, split_inputs_cp
+
+
+class DataType(Enum):
+    """Mirror of cosmos_predict1/diffusion/conditioner.py DataType (IMAGE/VIDEO)."""
+    IMAGE = "image"
+    VIDEO = "video"
+
+
+def _is_video(data_type) -> bool:
+    # accept our enum, the reference's enum, or a plain string
+    v = getattr(data_type, "value", data_type)
+    return str(v).lower().endswith("video")
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's parameter names (e.g. `to_q.0.weight`)."""
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer: bool = False):
+    *path, leaf = dotted.split(".")
+    mod = root
+    for p in path:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(leaf, tensor, persistent=True)
+    else:
+        mod.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+def _xavier_uniform_(t: torch.Tensor):
+    fan_out, fan_in = t.shape
+    a = math.sqrt(6.0 / (fan_in + fan_out))
+    return t.uniform_(-a, a)
+
+
+class VideoExtendGeneralDIT(nn.Module):
+    def __init__(
+        self,
+        max_img_h: int = 240,
+        max_img_w: int = 240,
+        max_frames: int = 128,
+        in_channels: int = 16 + 1,
+        out_channels: int = 16,
+        patch_spatial: int = 2,
+        patch_temporal: int = 1,
+        concat_padding_mask: bool = True,
+        block_config: str = "FA-CA-MLP",
+        model_channels: int = 4096,
+        num_blocks: int = 28,
+        num_heads: int = 32,
+        mlp_ratio: float = 4.0,
+        block_x_format: str = "THWBD",
+        crossattn_emb_channels: int = 1024,
+        use_cross_attn_mask: bool = False,
+        pos_emb_cls: str = "rope3d",
+        pos_emb_learnable: bool = False,
+        pos_emb_interpolation: str = "crop",
+        affline_emb_norm: bool = True,
+        use_adaln_lora: bool = True,
+        adaln_lora_dim: int = 256,
+        rope_h_extrapolation_ratio: float = 1.0,
+        rope_w_extrapolation_ratio: float = 1.0,
+        rope_t_extrapolation_ratio: float = 1.0,
+        extra_per_block_abs_pos_emb: bool = True,
+        extra_per_block_abs_pos_emb_type: str = "learnable",
+        extra_h_extrapolation_ratio: float = 1.0,
+        extra_w_extrapolation_ratio: float = 1.0,
+        extra_t_extrapolation_ratio: float = 1.0,
+        add_augment_sigma_embedding: bool = False,
+        device: Optional[torch.device | str] = None,
+        dtype: torch.dtype = torch.bfloat16,
+        init_weights: bool = True,
+    ) -> None:
+        super().__init__()
+        # the GEN3C-Cosmos-7B configuration space (config/base/net.py:23-43 + cosmos-1-diffusion-gen3c.py:38-43);
+        # anything else the reference class supports but GEN3C never instantiates is refused loudly.
+        if block_config.upper() != "FA-CA-MLP":
+            raise NotImplementedError(f"block_config {block_config!r}: only 'FA-CA-MLP' (GEN3C-Cosmos-7B) is built")
+        if block_x_format != "THWBD" or pos_emb_cls != "rope3d" or not use_adaln_lora or not affline_emb_norm:
+            raise NotImplementedError("only the faditv2 configuration (THWBD, rope3d, AdaLN-LoRA, affine emb norm) is built")
+        if not extra_per_block_abs_pos_emb or extra_per_block_abs_pos_emb_type.lower() != "learnable":
+            raise NotImplementedError("extra_per_block_abs_pos_emb must be the learnable per-axis embedding")
+        if use_cross_attn_mask or add_augment_sigma_embedding or pos_emb_learnable:
+            raise NotImplementedError("use_cross_attn_mask / add_augment_sigma_embedding / learnable rope are not used by GEN3C")
+        if model_channels // num_heads != 128:
+            raise NotImplementedError("head_dim must be 128 (HIP attention kernel)")
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the HIP path computes in bf16 (reference precision='bfloat16', config/base/model.py:29)")
+
+        self.max_img_h, self.max_img_w, self.max_frames = max_img_h, max_img_w, max_frames
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.patch_spatial, self.patch_temporal = patch_spatial, patch_temporal
+        self.concat_padding_mask = concat_padding_mask
+        self.model_channels, self.num_blocks, self.num_heads = model_channels, num_blocks, num_heads
+        self.mlp_hidden = int(model_channels * mlp_ratio)
+        self.crossattn_emb_channels = crossattn_emb_channels
+        self.adaln_lora_dim = adaln_lora_dim
+        self.block_x_format = block_x_format
+        self.head_dim = 128
+        self.base_fps = 24
+        self.cp_group = None
+        self.cp_size = None
+        self._cp_attn: Optional[ContextParallelAttention] = None
+        self._tables: Dict[tuple, tuple] = {}
+        self._packed = None
+
+        D, Hd = model_channels, self.head_dim
+        kw = dict(device=device, dtype=dtype)
+        E = lambda *shape: torch.empty(*shape, **kw)
+        emb_in = (in_channels + (1 if concat_padding_mask else 0)) * patch_spatial * patch_spatial * patch_temporal
+        self.patch_dim = emb_in
+
+        # ---- parameters, under the reference's names
+        _register(self, "x_embedder.proj.1.weight", E(D, emb_in))
+        len_h, len_w, len_t = max_img_h // patch_spatial, max_img_w // patch_spatial, max_frames // patch_temporal
+        _register(self, "pos_embedder.seq", torch.arange(max(len_h, len_w, len_t), dtype=torch.float, device=device), buffer=True)
+        _register(self, "extra_pos_embedder.pos_emb_h", E(len_h, D))
+        _register(self, "extra_pos_embedder.pos_emb_w", E(len_w, D))
+        _register(self, "extra_pos_embedder.pos_emb_t", E(len_t, D))
+        _register(self, "t_embedder.1.linear_1.weight", E(D, D))
+        _register(self, "t_embedder.1.linear_2.weight", E(3 * D, D))
+        for i in range(num_blocks):
+            pre = f"blocks.block{i}.blocks"
+            for j, ctx in ((0, D), (1, crossattn_emb_channels)):  # 0 = FA (self), 1 = CA (cross)
+                a = f"{pre}.{j}.block.attn"
+                _register(self, f"{a}.to_q.0.weight", E(D, D))
+                _register(self, f"{a}.to_q.1.weight", E(Hd))
+                _register(self, f"{a}.to_k.0.weight", E(D, ctx))
+                _register(self, f"{a}.to_k.1.weight", E(Hd))
+                _register(self, f"{a}.to_v.0.weight", E(D, ctx))
+                _register(self, f"{a}.to_out.0.weight", E(D, D))
+            _register(self, f"{pre}.2.block.layer1.weight", E(self.mlp_hidden, D))
+            _register(self, f"{pre}.2.block.layer2.weight", E(D, self.mlp_hidden))
+            for j in range(3):
+                _register(self, f"{pre}.{j}.adaLN_modulation.1.weight", E(adaln_lora_dim, D))
+                _register(self, f"{pre}.{j}.adaLN_modulation.2.weight", E(3 * D, adaln_lora_dim))
+        _register(self, "final_layer.linear.weight", E(patch_spatial * patch_spatial * patch_temporal * out_channels, D))
+        _register(self, "final_layer.adaLN_modulation.1.weight", E(adaln_lora_dim, D))
+        _register(self, "final_layer.adaLN_modulation.2.weight", E(2 * D, adaln_lora_dim))
+        _register(self, "affline_norm.weight", E(D))
+
+        # RoPE dimension split (position_embedding.py:106-124)
+        dim_h = Hd // 6 * 2
+        dim_t = Hd - 2 * dim_h
+        self._rope_dims = (dim_t, dim_h, dim_h)
+        self.h_ntk_factor = rope_h_extrapolation_ratio ** (dim_h / (dim_h - 2))
+        self.w_ntk_factor = rope_w_extrapolation_ratio ** (dim_h / (dim_h - 2))
+        self.t_ntk_factor = rope_t_extrapolation_ratio ** (dim_t / (dim_t - 2))
+
+        if init_weights:
+            self.initialize_weights()
+
+    # ------------------------------------------------------------------------------------------------ init / load
+    @torch.no_grad()
+    def initialize_weights(self, randomize_adaln: bool = False, seed: Optional[int] = None):
+        """Same distributions as GeneralDIT.initialize_weights (general_dit.py:180-203) and LearnablePosEmbAxis
+        (position_embedding.py:210-216). `randomize_adaln=True` replaces the zero-init of the last AdaLN layers by
+        N(0, 0.02^2) so that gates are non-zero on random weights - used by tests and bench only."""
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=self.affline_norm.weight.device)
+            gen.manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith(".to_q.1.weight") or name.endswith(".to_k.1.weight") or name == "affline_norm.weight":
+                p.fill_(1.0)
+            elif name.startswith("extra_pos_embedder."):
+                tmp = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+                nn.init.trunc_normal_(tmp, std=0.02, a=-2.0, b=2.0, generator=gen)  # timm trunc_normal_: cut at +-2 (absolute)
+                p.copy_(tmp)
+            elif name.startswith("t_embedder."):
+                p.normal_(0.0, 0.02, generator=gen)
+            elif name.endswith("adaLN_modulation.2.weight") and not name.startswith("final_layer."):
+                if randomize_adaln:
+                    p.normal_(0.0, 0.02, generator=gen)
+                else:
+                    p.zero_()
+            else:  # every other nn.Linear: xavier uniform
+                fan_out, fan_in = p.shape
+                a = math.sqrt(6.0 / (fan_in + fan_out))
+                p.uniform_(-a, a, generator=gen)
+        self._packed = None
+        self._tables.clear()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        # TE modules carry `_extra_state` blobs in the reference checkpoint; drop them like non_strict_load_model does
+        # (cosmos_predict1/diffusion/inference/inference_utils.py:240-242).
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("_extra_state")}
+        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._packed = None
+        self._tables.clear()
+        return out
+
+    # ------------------------------------------------------------------------------------------------ weight packing
+    def _pack(self):
+        """Fuse per-layer projection weights that share an input into one GEMM operand (done once per weight set)."""
+        if self._packed is not None:
+            return self._packed
+        P = dict(self.named_parameters())
+        blocks = []
+        for i in range(self.num_blocks):
+            pre = f"blocks.block{i}.blocks"
+            fa, ca, mlp = f"{pre}.0", f"{pre}.1", f"{pre}.2"
+            blocks.append(dict(
+                fa_qkv=torch.cat([P[f"{fa}.block.attn.to_q.0.weight"], P[f"{fa}.block.attn.to_k.0.weight"],
+                                  P[f"{fa}.block.attn.to_v.0.weight"]], dim=0).contiguous(),
+                fa_qn=P[f"{fa}.block.attn.to_q.1.weight"], fa_kn=P[f"{fa}.block.attn.to_k.1.weight"],
+                fa_out=P[f"{fa}.block.attn.to_out.0.weight"],
+                ca_q=P[f"{ca}.block.attn.to_q.0.weight"],
+                ca_kv=torch.cat([P[f"{ca}.block.attn.to_k.0.weight"], P[f"{ca}.block.attn.to_v.0.weight"]], dim=0).contiguous(),
+                ca_qn=P[f"{ca}.block.attn.to_q.1.weight"], ca_kn=P[f"{ca}.block.attn.to_k.1.weight"],
+                ca_out=P[f"{ca}.block.attn.to_out.0.weight"],
+                w1=P[f"{mlp}.block.layer1.weight"], w2=P[f"{mlp}.block.layer2.weight"],
+                ada=[(P[f"{pre}.{j}.adaLN_modulation.1.weight"], P[f"{pre}.{j}.adaLN_modulation.2.weight"]) for j in range(3)],
+            ))
+        self._packed = dict(blocks=blocks, P=P)
+        return self._packed
+
+    # ------------------------------------------------------------------------------------------------ context parallel
+    def enable_context_parallel(self, cp_group):
+        """general_dit.py:524-543. Self-attention K/V are exchanged by RCCL all-gather (see parallel.py)."""
+        import torch.distributed as dist
+        self.cp_group = cp_group
+        self.cp_size = dist.get_world_size(cp_group)
+        self._cp_attn = ContextParallelAttention(cp_group)
+        self._tables.clear()
+
+    def disable_context_parallel(self):
+        self.cp_group = None
+        self.cp_size = None
+        self._cp_attn = None
+        self._tables.clear()
+
+    @property
+    def is_context_parallel_enabled(self) -> bool:
+        return self.cp_group is not None
+
+    # ------------------------------------------------------------------------------------------------ tables
+    @torch.no_grad()
+    def _position_tables(self, B: int, T: int, Hp: int, Wp: int, fps: Optional[torch.Tensor], device) -> tuple:
+        """RoPE cos/sin [S,128] f32 (position_embedding.py:126-187) and the unit-RMS absolute position embedding
+        [S*B, D] bf16 (position_embedding.py:218-233 + attention.py:108-124). Input-independent: cached per
+        (B, T, H, W, fps, cp). With CP the tables are generated for the GLOBAL T and this rank's frames are sliced
+        out (position_embedding.py:66-79), so positions stay absolute."""
+        fps_val = None if fps is None else float(fps.flatten()[0])
+        cp = self.cp_size or 1
+        rank = 0
+        if self.cp_group is not None:
+            import torch.distributed as dist
+            rank = dist.get_rank(self.cp_group)
+        key = (B, T, Hp, Wp, fps_val, cp, rank, str(device))
+        if key in self._tables:
+            return self._tables[key]
+        Tg = T * cp
+        dim_t, dim_h, dim_w = self._rope_dims
+        seq = self.pos_embedder.seq.to(device=device, dtype=torch.float32)
+        rng_s = torch.arange(0, dim_h, 2, device=device)[: dim_h // 2].float() / dim_h
+        rng_t = torch.arange(0, dim_t, 2, device=device)[: dim_t // 2].float() / dim_t
+        h_freqs = 1.0 / ((10000.0 * self.h_ntk_factor) ** rng_s)
+        w_freqs = 1.0 / ((10000.0 * self.w_ntk_factor) ** rng_s)
+        t_freqs = 1.0 / ((10000.0 * self.t_ntk_factor) ** rng_t)
+        assert Hp <= self.max_img_h // self.patch_spatial and Wp <= self.max_img_w // self.patch_spatial
+        half_h = torch.outer(seq[:Hp], h_freqs)
+        half_w = torch.outer(seq[:Wp], w_freqs)
+        if fps_val is None:
+            assert Tg == 1, "T should be 1 for image batch."
+            half_t = torch.outer(seq[:Tg], t_freqs)
+        else:
+            half_t = torch.outer(seq[:Tg] / fps_val * self.base_fps, t_freqs)
+        half = torch.cat([
+            half_t[:, None, None, :].expand(Tg, Hp, Wp, -1),
+            half_h[None, :, None, :].expand(Tg, Hp, Wp, -1),
+            half_w[None, None, :, :].expand(Tg, Hp, Wp, -1),
+        ], dim=-1)
+        freqs = torch.cat([half, half], dim=-1)  # [Tg,Hp,Wp,128]
+        freqs = freqs[rank * T:(rank + 1) * T].reshape(T * Hp * Wp, 128).float()
+        cos, sin = torch.cos(freqs).contiguous(), torch.sin(freqs).contiguous()
+
+        pe_t = self.extra_pos_embedder.pos_emb_t[:Tg][rank * T:(rank + 1) * T]
+        pe_h = self.extra_pos_embedder.pos_emb_h[:Hp]
+        pe_w = self.extra_pos_embedder.pos_emb_w[:Wp]
+        emb = (pe_t[:, None, None, :] + pe_h[None, :, None, :]) + pe_w[None, None, :, :]  # bf16 adds, reference order
+        norm = torch.linalg.vector_norm(emb, dim=-1, keepdim=True, dtype=torch.float32)
+        norm = torch.add(1e-6, norm, alpha=math.sqrt(1.0 / emb.shape[-1]))
+        emb = emb / norm.to(emb.dtype)
+        D = emb.shape[-1]
+        emb = emb.reshape(T * Hp * Wp, 1, D).expand(-1, B, -1).reshape(T * Hp * Wp * B, D).contiguous()
+        self._tables[key] = (cos, sin, emb)
+        return self._tables[key]
+
+    # ------------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(
+        self,
+        x: torch.Tensor,
+        timesteps: torch.Tensor,
+        crossattn_emb: torch.Tensor,
+        crossattn_mask: Optional[torch.Tensor] = None,
+        fps: Optional[torch.Tensor] = None,
+        image_size: Optional[torch.Tensor] = None,
+        padding_mask: Optional[torch.Tensor] = None,
+        scalar_feature: Optional[torch.Tensor] = None,
+        data_type=DataType.VIDEO,
+        video_cond_bool: Optional[torch.Tensor] = None,
+        condition_video_indicator: Optional[torch.Tensor] = None,
+        condition_video_input_mask: Optional[torch.Tensor] = None,
+        condition_video_augment_sigma: Optional[torch.Tensor] = None,
+        condition_video_pose: Optional[torch.Tensor] = None,
+        **kwargs,
+    ) -> torch.Tensor:
+        """x: [B, 16, T_local, H, W] bf16 -> [B, 16, T_local, H, W] bf16 (general_dit_video_conditioned.py:58-132)."""
+        if scalar_feature is not None:
+            raise NotImplementedError("Scalar feature is not implemented yet.")  # same as the reference
+        B, C, T, H, W = x.shape
+        dev = x.device
+        if _is_video(data_type):
+            assert condition_video_input_mask is not None, "condition_video_input_mask is required for video data type"
+            if self.cp_group is not None:
+                condition_video_input_mask = split_inputs_cp(condition_video_input_mask, 2, self.cp_group)
+                if condition_video_indicator is not None:
+                    condition_video_indicator = split_inputs_cp(condition_video_indicator, 2, self.cp_group)
+                if condition_video_pose is not None:
+                    condition_video_pose = split_inputs_cp(condition_video_pose, 2, self.cp_group)
+            parts = [x, condition_video_input_mask.to(x.dtype)]
+            if condition_video_pose is not None:
+                parts.append(condition_video_pose.to(x.dtype))
+            x = torch.cat(parts, dim=1)
+        if self.concat_padding_mask:
+            pm = _nearest_resize(padding_mask, (H, W)).to(x.dtype)  # torchvision NEAREST resize (general_dit.py:305-307)
+            x = torch.cat([x, pm[:, None, None, :, :].expand(B, 1, T, H, W)], dim=1)
+        assert x.shape[1] * self.patch_spatial ** 2 * self.patch_temporal == self.patch_dim, \
+            f"channel mismatch: got {x.shape[1]} input channels"
+
+        ps, pt = self.patch_spatial, self.patch_temporal
+        Tp, Hp, Wp = T // pt, H // ps, W // ps
+        S = Tp * Hp * Wp
+        D = self.model_channels
+        # patch gather "b c (t r) (h m) (w n) -> (t h w) b (c r m n)"  (blocks.py:154-159 + THWBD order)
+        patches = (x.view(B, -1, Tp, pt, Hp, ps, Wp, ps).permute(2, 4, 6, 0, 1, 3, 5, 7)
+                   .reshape(S * B, self.patch_dim).contiguous())
+
+        pk = self._pack()
+        P = pk["P"]
+        cos, sin, pos_emb = self._position_tables(B, Tp, Hp, Wp, fps, dev)
+
+        xs = ops.gemm_nt(patches, P["x_embedder.proj.1.weight"])  # [S*B, D]
+
+        # ---- timestep embedding (blocks.py:38-80) + affine RMSNorm (general_dit.py:173-177)
+        ts = timesteps.flatten()
+        half = D // 2
+        expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / (half - 0.0)
+        ang = ts[:, None].float() * torch.exp(expo)[None, :]
+        t_sin = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ts.dtype if ts.dtype.is_floating_point else torch.bfloat16)
+        t_sin = t_sin.to(torch.bfloat16).contiguous()  # [B, D]
+        if t_sin.shape[0] != B:
+            t_sin = t_sin.expand(B, -1).contiguous()
+        h1 = ops.gemv(t_sin, P["t_embedder.1.linear_1.weight"])
+        adaln_lora = ops.gemv(h1, P["t_embedder.1.linear_2.weight"], act_in=1)  # [B, 3D]
+        tf = t_sin.float()
+        emb = (tf * torch.rsqrt(tf.pow(2).mean(-1, keepdim=True) + 1e-6) * P["affline_norm.weight"].float()).to(torch.bfloat16)
+
+        # ---- context
+        M = crossattn_emb.shape[1]
+        ctx = crossattn_emb.to(torch.bfloat16).permute(1, 0, 2).reshape(M * B, -1).contiguous()  # rows (m, b)
+
+        nH = self.num_heads
+        for blk in pk["blocks"]:
+            ops.add_inplace(xs, pos_emb)
+            # -- self attention
+            shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
+            h = ops.layernorm_modulate(xs, shift, scale)
+            qkv = ops.gemm_nt(h, blk["fa_qkv"])  # [S*B, 3D]
+            q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH)
+            k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH)
+            v = qkv[:, 2 * D:]
+            if self._cp_attn is not None:
+                o = self._cp_attn(q, k, v, S, B, nH)
+            else:
+                vt = ops.transpose_v(v, S, B, nH)
+                o = ops.flash_attn(q, k, vt, S, S, B, nH)
+            ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
+            # -- cross attention (unmasked over all M context tokens, general_dit.py:407-410)
+            shift, scale, gate = self._modulation(emb, blk["ada"][1], adaln_lora, 3)
+            h = ops.layernorm_modulate(xs, shift, scale)
+            q = ops.gemm_nt(h, blk["ca_q"])
+            q = ops.qk_rmsnorm_rope(q, blk["ca_qn"], None, None, S, B, nH)
+            kv = ops.gemm_nt(ctx, blk["ca_kv"])  # [M*B, 2D]
+            k = ops.qk_rmsnorm_rope(kv[:, :D], blk["ca_kn"], None, None, M, B, nH)
+            vt = ops.transpose_v(kv[:, D:], M, B, nH)
+            o = ops.flash_attn(q, k, vt, S, M, B, nH)
+            ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
+            # -- MLP
+            shift, scale, gate = self._modulation(emb, blk["ada"][2], adaln_lora, 3)
+            h = ops.layernorm_modulate(xs, shift, scale)
+            u = ops.gemm_nt(h, blk["w1"], epilogue=ops.EPI_GELU)
+            ops.gemm_nt(u, blk["w2"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
+
+        # ---- final layer (blocks.py:222-242) + unpatchify (general_dit.py:348-357)
+        fl = (P["final_layer.adaLN_modulation.1.weight"], P["final_layer.adaLN_modulation.2.weight"])
+        shift, scale = self._modulation(emb, fl, adaln_lora[:, : 2 * D], 2)
+        h = ops.layernorm_modulate(xs, shift, scale)
+        y = ops.gemm_nt(h, P["final_layer.linear.weight"])  # [S*B, p1*p2*t*C]
+        Co = self.out_channels
+        y = (y.view(Tp, Hp, Wp, B, ps, ps, pt, Co).permute(3, 7, 0, 6, 1, 4, 2, 5)
+             .reshape(B, Co, Tp * pt, Hp * ps, Wp * ps))
+        return y.contiguous()
+
+    def _modulation(self, emb, ada, lora, n):
+        """(shift, scale[, gate]) = chunk_n( W2 . (W1 . SiLU(emb)) + adaln_lora )   (blocks.py:442-447)"""
+        w1, w2 = ada
+        mid = ops.gemv(emb, w1, act_in=1)
+        mod = ops.gemv(mid, w2, add=lora)  # [B, n*D]
+        D = self.model_channels
+        return tuple(mod[:, i * D:(i + 1) * D] for i in range(n))
+
+
+def _nearest_resize(mask: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """torchvision.transforms.functional.resize(..., NEAREST) on a [B,1,h,w] / [B,h,w] mask == F.interpolate nearest."""
+    m = mask
+    squeeze = False
+    if m.dim() == 3:
+        m = m.unsqueeze(1)
+        squeeze = True
+    if tuple(m.shape[-2:]) != tuple(size):
+        m = torch.nn.functional.interpolate(m.float(), size=size, mode="nearest").to(mask.dtype)
+    # reference keeps [B, 1, H, W] then unsqueeze(1) -> here return [B, H, W]-like squeezed channel
+    return m[:, 0] if (m.dim() == 4) else m

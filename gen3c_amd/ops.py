@@ -1,0 +1,236 @@
+"""Thin torch-tensor front end over the C ABI (include/gen3c_hip.h).
+
+torch is used for what it is good at here - device memory and streams. Every function hands raw device pointers,
+shapes and the current HIP stream to libgen3c_hip.so; none of them computes anything in PyTorch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_GELU, EPI_GATED_RESIDUAL, EPI_BIAS = 0, 1, 2, 3
+
+# bench.py switches this to a list to collect (kernel, shape, HipTimer) triples for the dominant kernel: hipEvents are
+# recorded on the launch stream right around the launch (a handful of events per step - no measurable overhead).
+_KERNEL_TIMERS = None
+
+
+def enable_kernel_timers(on: bool = True):
+    global _KERNEL_TIMERS
+    _KERNEL_TIMERS = [] if on else None
+
+
+def collected_kernel_timers():
+    return list(_KERNEL_TIMERS or [])
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.bfloat16) -> int:
+    if not t.is_cuda:
+        raise _lib.Gen3cHipError(f"{name}: expected a GPU (HIP) tensor, got device {t.device}; gen3c_amd has no CPU path")
+    if t.dtype != dtype:
+        raise _lib.Gen3cHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rowmajor2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.Gen3cHipError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+            gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T).  gate: [rows, N] (row = m % rows); residual: [M, N]."""
+    M, K, lda = _rowmajor2d(a, "a")
+    N, Kw, ldw = _rowmajor2d(w, "w")
+    if K != Kw:
+        raise _lib.Gen3cHipError(f"gemm_nt: K mismatch {K} vs {Kw}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    Mo, No, ldc = _rowmajor2d(out, "out")
+    assert (Mo, No) == (M, N)
+    gp, grows, ldg, rp, ldr = 0, 1, 0, 0, 0
+    if gate is not None:
+        grows, gn, ldg = _rowmajor2d(gate, "gate")
+        assert gn == N
+        gp = _dev(gate, "gate")
+    if residual is not None:
+        rm, rn, ldr = _rowmajor2d(residual, "residual")
+        assert (rm, rn) == (M, N)
+        rp = _dev(residual, "residual")
+    lib = _lib.load()
+    _lib.check(lib.g3_gemm_bf16_nt(_dev(a, "a"), lda, _dev(w, "w"), ldw, _dev(out, "out"), ldc, M, N, K, epilogue, gp, grows,
+                                   ldg, rp, ldr, _stream()), "g3_gemm_bf16_nt")
+    return out
+
+
+def gemv(a: torch.Tensor, w: torch.Tensor, add: Optional[torch.Tensor] = None, act_in: int = 0,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M<=8, N] = act_in(a) @ w^T (+ add)."""
+    M, K, lda = _rowmajor2d(a, "a")
+    N, Kw, ldw = _rowmajor2d(w, "w")
+    assert K == Kw
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    ap, ldadd = 0, 0
+    if add is not None:
+        am, an, ldadd = _rowmajor2d(add, "add")
+        assert (am, an) == (M, N)
+        ap = _dev(add, "add")
+    lib = _lib.load()
+    _lib.check(lib.g3_gemv_bf16(_dev(a, "a"), lda, _dev(w, "w"), ldw, ap, ldadd, _dev(out, "out"), out.stride(0), M, N, K,
+                                act_in, _stream()), "g3_gemv_bf16")
+    return out
+
+
+def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       eps: float = 1e-6) -> torch.Tensor:
+    """x: [rows, D] (rows = (s, b), b fastest); shift/scale: [B, D]."""
+    rows, D, ldx = _rowmajor2d(x, "x")
+    B, Ds, ldmod = _rowmajor2d(shift, "shift")
+    assert Ds == D and scale.shape == shift.shape and scale.stride(0) == ldmod
+    if out is None:
+        out = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.g3_layernorm_modulate_bf16(_dev(x, "x"), ldx, _dev(shift, "shift"), _dev(scale, "scale"), ldmod, B,
+                                              _dev(out, "out"), out.stride(0), rows, D, eps, _stream()),
+               "g3_layernorm_modulate_bf16")
+    return out
+
+
+def qk_rmsnorm_rope(x: torch.Tensor, weight: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
+                    S: int, B: int, H: int, out: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    """x: [S*B, >=H*128] view (row stride arbitrary), per-head RMSNorm + optional RoPE -> out [S*B, H*128]."""
+    rows, width, ld_in = _rowmajor2d(x, "x")
+    assert rows == S * B and width == H * 128
+    if out is None:
+        out = torch.empty((rows, H * 128), dtype=torch.bfloat16, device=x.device)
+    cp = sp = 0
+    if cos is not None:
+        assert cos.shape == (S, 128) and sin.shape == (S, 128) and cos.is_contiguous() and sin.is_contiguous()
+        cp, sp = _dev(cos, "cos", torch.float32), _dev(sin, "sin", torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.g3_qk_rmsnorm_rope_bf16(_dev(x, "x"), ld_in, _dev(weight, "weight"), cp, sp, _dev(out, "out"),
+                                           out.stride(0), S, B, H, 128, eps, _stream()), "g3_qk_rmsnorm_rope_bf16")
+    return out
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def transpose_v(v: torch.Tensor, S: int, B: int, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """v: [S*B, H*128] view -> V^T [B, H, 128, ceil64(S)] with a zero tail."""
+    rows, width, ld_in = _rowmajor2d(v, "v")
+    assert rows == S * B and width == H * 128
+    ldvt = ceil_to(S, 64)
+    if out is None:
+        out = torch.empty((B, H, 128, ldvt), dtype=torch.bfloat16, device=v.device)
+    assert out.shape == (B, H, 128, ldvt) and out.is_contiguous()
+    lib = _lib.load()
+    _lib.check(lib.g3_transpose_v_bf16(_dev(v, "v"), ld_in, _dev(out, "out"), ldvt, S, B, H, 128, _stream()),
+               "g3_transpose_v_bf16")
+    return out
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv: int, B: int, H: int,
+               out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """q: [Sq*B, H*128], k: [Skv*B, H*128] (rows (s,b), b fastest), vt: [B, H, 128, ldvt] -> out [Sq*B, H*128]."""
+    qr, qw, ldq = _rowmajor2d(q, "q")
+    kr, kw, ldk = _rowmajor2d(k, "k")
+    assert qr == Sq * B and kr == Skv * B and qw == H * 128 and kw == H * 128
+    assert vt.dim() == 4 and vt.shape[:3] == (B, H, 128) and vt.is_contiguous()
+    ldvt = vt.shape[3]
+    if out is None:
+        out = torch.empty((Sq * B, H * 128), dtype=torch.bfloat16, device=q.device)
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(128)
+    lib = _lib.load()
+    timer = None
+    if _KERNEL_TIMERS is not None:
+        timer = HipTimer()
+        timer.start()
+    _lib.check(lib.g3_flash_attn_fwd_bf16(
+        _dev(q, "q"), ldq * B, ldq, 128,
+        _dev(k, "k"), ldk * B, ldk, 128,
+        _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,
+        _dev(out, "out"), out.stride(0) * B, out.stride(0), 128,
+        Sq, Skv, B, H, 128, float(softmax_scale), _stream()), "g3_flash_attn_fwd_bf16")
+    if timer is not None:
+        timer.stop()
+        _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H), timer))
+    return out
+
+
+def add_inplace(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    lib = _lib.load()
+    _lib.check(lib.g3_add_inplace_bf16(_dev(x, "x"), _dev(y, "y"), x.numel(), _stream()), "g3_add_inplace_bf16")
+    return x
+
+
+def edm_prepare_input(xt, gt_latent, noise, indicator, T: int, hw: int, augment_sigma: float, c_in_aug: float,
+                      c_in_bf16: float, c_in_step: float):
+    """-> (new_xt, new_xt_scaled), both bf16 like xt. See g3_edm_prepare_input_bf16."""
+    assert xt.is_contiguous() and gt_latent.is_contiguous() and noise.is_contiguous() and indicator.is_contiguous()
+    assert xt.shape == gt_latent.shape == noise.shape and indicator.numel() == T
+    new_xt, new_xt_scaled = torch.empty_like(xt), torch.empty_like(xt)
+    lib = _lib.load()
+    _lib.check(lib.g3_edm_prepare_input_bf16(_dev(xt, "xt"), _dev(gt_latent, "gt_latent"), _dev(noise, "noise", torch.float32),
+                                             _dev(indicator, "indicator", torch.float32), _dev(new_xt, "new_xt"),
+                                             _dev(new_xt_scaled, "new_xt_scaled"), xt.numel(), T, hw, augment_sigma, c_in_aug,
+                                             c_in_bf16, c_in_step, _stream()), "g3_edm_prepare_input_bf16")
+    return new_xt, new_xt_scaled
+
+
+def edm_cfg_euler_step(out_cond, out_uncond, new_xt, gt_latent, indicator, T: int, hw: int, guidance: float,
+                       c_skip_bf16: float, c_out_bf16: float, c_skip: float, c_out: float, sigma: float, sigma_next: float):
+    """-> xt_next (bf16). See g3_edm_cfg_euler_step_bf16."""
+    for t in (out_cond, out_uncond, new_xt, gt_latent, indicator):
+        assert t.is_contiguous()
+    assert out_cond.shape == out_uncond.shape == new_xt.shape == gt_latent.shape
+    xt_next = torch.empty_like(new_xt)
+    lib = _lib.load()
+    _lib.check(lib.g3_edm_cfg_euler_step_bf16(_dev(out_cond, "out_cond"), _dev(out_uncond, "out_uncond"), _dev(new_xt, "new_xt"),
+                                              _dev(gt_latent, "gt_latent"), _dev(indicator, "indicator", torch.float32),
+                                              _dev(xt_next, "xt_next"), new_xt.numel(), T, hw, guidance, c_skip_bf16, c_out_bf16,
+                                              c_skip, c_out, sigma, sigma_next, _stream()), "g3_edm_cfg_euler_step_bf16")
+    return xt_next
+
+
+class HipTimer:
+    """hipEvent pair recorded on torch's current stream through the C ABI (used by bench.py for kernel timing)."""
+
+    def __init__(self):
+        import ctypes as C
+        self._lib = _lib.load()
+        self._a, self._b = C.c_void_p(), C.c_void_p()
+        _lib.check(self._lib.g3_event_create(C.byref(self._a)))
+        _lib.check(self._lib.g3_event_create(C.byref(self._b)))
+
+    def start(self):
+        _lib.check(self._lib.g3_event_record(self._a, _stream()))
+
+    def stop(self):
+        _lib.check(self._lib.g3_event_record(self._b, _stream()))
+
+    def elapsed_ms(self) -> float:
+        import ctypes as C
+        ms = C.c_float(0)
+        _lib.check(self._lib.g3_event_elapsed_ms(self._a, self._b, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self._lib.g3_event_destroy(self._a)
+            self._lib.g3_event_destroy(self._b)
+        except Exception:
+            pass

@@ -1,0 +1,188 @@
+"""Context parallelism for the DiT over RCCL / xGMI (one process per GPU, torch.distributed backend "nccl" = RCCL).
+
+Mirrors the reference surface
+  * split_inputs_cp / cat_outputs_cp / broadcast   (cosmos_predict1/diffusion/module/parallel.py:25-163)
+  * distributed.init()                             (cosmos_predict1/utils/distributed.py:49-79)
+  * the slice of megatron-core `parallel_state` the GEN3C CLIs touch (gen3c_single_image.py:248-255, 480-484)
+but NOT its communication pattern. The reference lets TransformerEngine run a P2P *ring* over the CP ranks
+(general_dit.py:540-541), which on xGMI's point-to-point mesh is bound by a single ~153 GB/s link. Here every rank's
+K / V shard is exchanged with a direct all-gather (all 7 links busy at once), split into head groups so that the
+attention kernel of group g runs on the compute stream while RCCL is still gathering group g+1.
+
+Token layout: rows are (s, b) pairs with b fastest and the latent frames sharded contiguously over ranks, so a
+rank-major all-gather of row blocks IS the global (s, b) order - no re-sort after the collective.
+"""
+from __future__ import annotations
+
+import os
+from datetime import timedelta
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reference-compatible helpers
+# ------------------------------------------------------------------------------------------------------------------
+def split_inputs_cp(x: torch.Tensor, seq_dim: int, cp_group) -> torch.Tensor:
+    """This rank's contiguous slice of `x` along `seq_dim` (parallel.py:25-53)."""
+    cp_size = dist.get_world_size(cp_group)
+    rank = dist.get_rank(cp_group)
+    n = x.shape[seq_dim]
+    assert n % cp_size == 0, f"{n} cannot divide cp_size {cp_size}"
+    step = n // cp_size
+    return x.narrow(seq_dim, rank * step, step).contiguous()
+
+
+def cat_outputs_cp(x: torch.Tensor, seq_dim: int, cp_group) -> torch.Tensor:
+    """All-gather the per-rank slices and concatenate them along `seq_dim` (parallel.py:56-87)."""
+    world = dist.get_world_size(cp_group)
+    parts = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(parts, x.contiguous(), group=cp_group)
+    return torch.cat(parts, dim=seq_dim)
+
+
+def broadcast(item, to_tp: bool = True, to_cp: bool = True):
+    """Broadcast a tensor / picklable object from the lowest rank of the CP group (parallel.py:90-163).
+    There is no tensor parallelism on this path (Attention.tp_size = 1, attention.py:205): `to_tp` is accepted
+    and ignored."""
+    if not parallel_state.is_initialized():
+        return item
+    group = parallel_state.get_context_parallel_group()
+    if not (to_cp and dist.get_world_size(group) > 1):
+        return item
+    src = min(dist.get_process_group_ranks(group))
+    if isinstance(item, torch.Tensor):
+        dev = item.device
+        if dist.get_rank() == src:
+            shape = torch.tensor(item.shape, dtype=torch.long, device=dev)
+        else:
+            shape = torch.empty(item.dim(), dtype=torch.long, device=dev)
+        dist.broadcast(shape, src, group=group)
+        if dist.get_rank() != src:
+            item = item.new_empty(shape.tolist())
+        item = item.contiguous()
+        dist.broadcast(item, src, group=group)
+        return item
+    if item is not None:
+        box = [item]
+        dist.broadcast_object_list(box, src, group=group)
+        return box[0]
+    return item
+
+
+class _ParallelState:
+    """The part of megatron.core.parallel_state that gen3c_*.py use, for a pure context-parallel job."""
+
+    def __init__(self):
+        self._cp_group = None
+
+    def initialize_model_parallel(self, context_parallel_size: int = 1, **_unused):
+        world = dist.get_world_size()
+        assert world % context_parallel_size == 0, f"world size {world} not divisible by cp {context_parallel_size}"
+        my_group = None
+        for start in range(0, world, context_parallel_size):
+            ranks = list(range(start, start + context_parallel_size))
+            g = dist.new_group(ranks)
+            if dist.get_rank() in ranks:
+                my_group = g
+        self._cp_group = my_group
+
+    def is_initialized(self) -> bool:
+        return self._cp_group is not None
+
+    def get_context_parallel_group(self):
+        assert self._cp_group is not None, "context parallel group is not initialized"
+        return self._cp_group
+
+    def get_context_parallel_world_size(self) -> int:
+        return dist.get_world_size(self._cp_group) if self._cp_group is not None else 1
+
+    def get_context_parallel_rank(self) -> int:
+        return dist.get_rank(self._cp_group) if self._cp_group is not None else 0
+
+    def get_tensor_model_parallel_group(self):
+        return None
+
+    def get_tensor_model_parallel_world_size(self) -> int:
+        return 1
+
+    def destroy_model_parallel(self):
+        self._cp_group = None
+
+
+parallel_state = _ParallelState()
+
+
+def init_distributed(backend: Optional[str] = None) -> int:
+    """Counterpart of cosmos_predict1.utils.distributed.init (utils/distributed.py:49-79) without the NVIDIA-only
+    parts (pynvml affinity, libcudart cudaDeviceSetLimit). One process per GPU; rendezvous via env:// as set by
+    torchrun. Returns the local device index."""
+    local_rank = int(os.getenv("LOCAL_RANK", 0))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (required by RCCL on this driver)
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        timeout = timedelta(seconds=int(os.getenv("TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC", 1800)))
+        dist.init_process_group(backend=backend, init_method="env://", timeout=timeout)
+    return local_rank
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# context-parallel self-attention
+# ------------------------------------------------------------------------------------------------------------------
+def _default_backend():
+    from . import ops
+    return dict(
+        pack=lambda t: t.contiguous(),
+        transpose_v=lambda v, S, B, H: ops.transpose_v(v, S, B, H),
+        attention=lambda q, k, vt, Sq, Skv, B, H, out: ops.flash_attn(q, k, vt, Sq, Skv, B, H, out=out),
+    )
+
+
+class ContextParallelAttention:
+    """softmax(Q_local K_all^T) V_all for a token-sharded sequence.
+
+    q, k, v: [S_local*B, H*128] (v may be a strided column view). K and V shards are all-gathered head-group by
+    head-group (async, RCCL stream) and consumed by the attention kernel in the same order, so only the first
+    group's exchange is exposed; the rest hides under the attention of earlier groups.
+
+    `backend` (dict of callables pack / transpose_v / attention) exists so the sharding + collective schedule can be
+    exercised on CPU with gloo in tests; the product path always uses the HIP kernels.
+    """
+
+    def __init__(self, cp_group, head_groups: int = 4, backend: Optional[dict] = None):
+        self.group = cp_group
+        self.world = dist.get_world_size(cp_group)
+        self.head_groups = head_groups
+        self.backend = backend
+
+    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int) -> torch.Tensor:
+        be = self.backend or _default_backend()
+        G = self.head_groups
+        while H % G != 0:
+            G -= 1
+        Hg = H // G
+        W = Hg * 128
+        rows = S_local * B
+        S_all = S_local * self.world
+        out = torch.empty((rows, H * 128), dtype=q.dtype, device=q.device)
+        works = []
+        for g in range(G):
+            ks = be["pack"](k[:, g * W:(g + 1) * W])
+            vs = be["pack"](v[:, g * W:(g + 1) * W])
+            kf = torch.empty((self.world * rows, W), dtype=k.dtype, device=k.device)
+            vf = torch.empty((self.world * rows, W), dtype=v.dtype, device=v.device)
+            wk = dist.all_gather_into_tensor(kf, ks, group=self.group, async_op=True)
+            wv = dist.all_gather_into_tensor(vf, vs, group=self.group, async_op=True)
+            works.append((wk, wv, kf, vf, ks, vs))
+        for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
+            wk.wait()
+            wv.wait()
+            vt = be["transpose_v"](vf, S_all, B, Hg)
+            be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
+        return out

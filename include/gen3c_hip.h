@@ -1,0 +1,106 @@
+/*
+ * gen3c_hip.h - C ABI of libgen3c_hip.so: the MI355X (gfx950) kernels of the GEN3C-Cosmos-7B denoising path.
+ *
+ * The reference (nv-tlabs/GEN3C, a Cosmos-Predict1 fork) has no FFI boundary for this path: the hot operators sit
+ * behind Python module seams and third-party CUDA libraries (TransformerEngine, cuBLAS via nn.Linear, ATen
+ * index_put_, NVIDIA Warp).  Each entry point below names the reference call site(s) it replaces; INTEGRATION.md
+ * shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless marked "host"; nothing is allocated or freed inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream;
+ *   - tensors are bf16 (uint16 storage) unless the name says f32; leading dims / strides are in ELEMENTS;
+ *   - return value: 0 = G3_OK, non-zero = error (g3_last_error() returns a thread-local message);
+ *   - thread-compatible: no mutable global state besides lazily-set kernel attributes.
+ */
+#ifndef GEN3C_HIP_H
+#define GEN3C_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G3_OK 0
+#define G3_ERR_ARG 1
+#define G3_ERR_LAUNCH 2
+
+/* epilogues of g3_gemm_bf16_nt */
+#define G3_EPI_NONE 0           /* C = A.W^T                                   */
+#define G3_EPI_GELU 1           /* C = gelu_erf(A.W^T)      attention.py:86,94-99 (GPT2FeedForward)            */
+#define G3_EPI_GATED_RESIDUAL 2 /* C = R + gate[m%rows] * (A.W^T)   blocks.py:455-471 (x + gate * block(...))   */
+#define G3_EPI_BIAS 3           /* C = A.W^T + bias[m%rows]                                                     */
+
+const char* g3_last_error(void);
+int g3_abi_version(void);
+int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name /*host*/, int arch_name_len);
+
+/* hipEvent helpers (opaque handles) so a host can time a stream without linking HIP itself. */
+int g3_event_create(void** ev);
+int g3_event_record(void* ev, void* stream);
+int g3_event_elapsed_ms(void* start, void* stop, float* ms /*host*/);
+int g3_event_destroy(void* ev);
+
+/* ---- DiT linears ---------------------------------------------------------------------------------------------
+ * C[M,N] = epi(A[M,K] . W[N,K]^T): replaces nn.Linear(bias=False) in Attention.to_q/to_k/to_v/to_out
+ * (cosmos_predict1/diffusion/module/attention.py:207-223), GPT2FeedForward.layer1/layer2 (attention.py:61-62),
+ * PatchEmbed.proj (blocks.py:160-162) and FinalLayer.linear (blocks.py:205-206).
+ * Needs K, lda, ldw multiples of 8; N, ldc (ldg, ldr) multiples of 4. gate/bias is [gate_rows][ldg]. */
+int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                    int epilogue, const void* gate, int gate_rows, int64_t ldg, const void* residual, int64_t ldr,
+                    void* stream);
+
+/* out[M<=8][N] = (act_in(a) . w^T) (+ add): TimestepEmbedding (blocks.py:60-80) and adaLN_modulation
+ * (blocks.py:411-415, 442-447; FinalLayer blocks.py:212-216, 230). act_in: 0 none, 1 SiLU. */
+int g3_gemv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* add, int64_t ldadd, void* out,
+                 int64_t ldo, int M, int N, int K, int act_in, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------------------------
+ * O = softmax(Q K^T * softmax_scale) V, no mask, head_dim 128: replaces TransformerEngine DotProductAttention
+ * (attention.py:228-238, 288). Element (s, b, h, d) of Q is at q + s*q_row + b*q_batch + h*q_head + d (same for K, O);
+ * V is passed TRANSPOSED: element (b, h, d, kv) at vt + b*vt_batch + h*vt_head + d*vt_row + kv, with
+ * vt_row >= S_kv rounded up to 8 and the tail [S_kv, vt_row) zero (g3_transpose_v_bf16 writes exactly this). */
+int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row,
+                           int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch,
+                           int64_t vt_head, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv,
+                           int B, int H, int head_dim, float softmax_scale, void* stream);
+
+/* V [S][B][H][128] (row stride ld_in) -> V^T [B][H][128][ldvt], zero-filling kv in [S, ldvt). */
+int g3_transpose_v_bf16(const void* v, int64_t ld_in, void* vt, int64_t ldvt, int S, int B, int H, int head_dim,
+                        void* stream);
+
+/* ---- norms -----------------------------------------------------------------------------------------------------
+ * out = LayerNorm(x; no affine, eps) * (1 + scale[row % mod_rows]) + shift[row % mod_rows]
+ * replaces DITBuildingBlock.norm_state + adaln_norm_state (blocks.py:339-341, 408) and FinalLayer (blocks.py:204, 239). */
+int g3_layernorm_modulate_bf16(const void* x, int64_t ldx, const void* shift, const void* scale, int64_t ldmod,
+                               int mod_rows, void* out, int64_t ldo, int rows, int D, float eps, void* stream);
+
+/* per-head RMSNorm(weight[128], eps) then (optional) non-interleaved RoPE with f32 cos/sin tables [S][128]:
+ * replaces te.pytorch.RMSNorm + apply_rotary_pos_emb(fused=True) in Attention.cal_qkv (attention.py:262-280).
+ * in/out rows are (s, b) pairs, b fastest; cos_table == sin_table == NULL skips RoPE (cross-attention, k of context). */
+int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, const float* cos_table,
+                            const float* sin_table, void* out, int64_t ld_out, int S, int B, int H, int head_dim,
+                            float eps, void* stream);
+
+/* x += y (n % 8 == 0): "x = x + extra_per_block_pos_emb" (blocks.py:547-548). */
+int g3_add_inplace_bf16(void* x, const void* y, int64_t n, void* stream);
+
+/* ---- EDM-Euler sampler step (model_v2w.py:130-149, 201-259; diffusers 0.32.2 EDMEulerScheduler) ------------------
+ * Two fused elementwise passes around the two network calls of one denoise step, over a [B,C,T,H,W] latent of n
+ * elements (hw = H*W, indicator = f32 [T], 1 on conditioning frames). Scalar coefficients are evaluated by the host
+ * in the dtypes the reference uses (see gen3c_amd/sampler.py) and passed as floats.
+ *   prepare: new_xt = bf16(ind*((gt+noise*aug)*c_in_aug/c_in_bf16) + (1-ind)*xt); new_xt_scaled = bf16(new_xt*c_in_step)
+ *   step   : net = cond + g*(cond-uncond); replace conditioning frames by the (un-preconditioned) latent; Euler update. */
+int g3_edm_prepare_input_bf16(const void* xt, const void* gt_latent, const float* noise, const float* indicator,
+                              void* new_xt, void* new_xt_scaled, int64_t n, int T, int hw, float augment_sigma,
+                              float c_in_aug, float c_in_bf16, float c_in_step, void* stream);
+int g3_edm_cfg_euler_step_bf16(const void* out_cond, const void* out_uncond, const void* new_xt, const void* gt_latent,
+                               const float* indicator, void* xt_next, int64_t n, int T, int hw, float guidance,
+                               float c_skip_bf16, float c_out_bf16, float c_skip, float c_out, float sigma,
+                               float sigma_next, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEN3C_HIP_H */

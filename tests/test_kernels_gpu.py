@@ -1,0 +1,223 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against fp32 references.
+
+Tolerances (stated per test): operands are bf16, accumulation fp32, outputs rounded once to bf16 - so the expected
+error vs an fp32 evaluation of the same bf16 operands is ~2^-9 relative per output (one bf16 rounding) plus
+accumulation-order noise.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _report(name, got, ref):
+    err = (got.float() - ref.float()).abs()
+    print(f"[{name}] rel_l2={_rel_l2(got, ref):.3e} max_abs={float(err.max()):.3e} ref_absmax={float(ref.abs().max()):.3e}")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 260, 136), (1000, 64, 328), (56, 1024, 4096),
+                                   (2048, 4096, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_nt(M, N, K, epi):
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K + epi)
+    a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(1, N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+        out = ops.gemm_nt(a, w, epilogue=ops.EPI_GELU)
+    elif epi == 2:
+        ref = res.float() + gate.float() * ref
+        out = ops.gemm_nt(a, w, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=res)
+    elif epi == 3:
+        ref = ref + gate.float()
+        out = ops.gemm_nt(a, w, epilogue=ops.EPI_BIAS, gate=gate)
+    else:
+        out = ops.gemm_nt(a, w)
+    torch.cuda.synchronize()
+    _report(f"gemm {M}x{N}x{K} epi{epi}", out, ref)
+    # one bf16 rounding of the output (2^-8 relative worst case) + fp32 accumulation noise
+    torch.testing.assert_close(out.float(), ref, rtol=1.0 / 128, atol=2e-2)
+    assert _rel_l2(out, ref) < 4e-3
+
+
+def test_gemm_inplace_residual_and_gate_rows():
+    from gen3c_amd import ops
+    dev = _dev()
+    B, S, N, K = 2, 200, 512, 256
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn(S * B, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(B, 3 * N, device=dev, generator=g).to(torch.bfloat16)[:, N:2 * N]  # strided rows
+    x = torch.randn(S * B, N, device=dev, generator=g).to(torch.bfloat16)
+    ref = x.float() + gate.float().repeat(S, 1) * (a.float() @ w.float().t())
+    ops.gemm_nt(a, w, out=x, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=x)
+    torch.cuda.synchronize()
+    _report("gemm inplace", x, ref)
+    torch.testing.assert_close(x.float(), ref, rtol=1.0 / 128, atol=2e-2)
+
+
+def _attn_ref(q, k, v, Sq, Skv, B, H):
+    qf = q.float().view(Sq, B, H, 128).permute(1, 2, 0, 3)
+    kf = k.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+    vf = v.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+    p = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(128), dim=-1)
+    return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
+
+
+@pytest.mark.parametrize("Sq,Skv,B,H", [(256, 256, 1, 1), (512, 512, 1, 2), (300, 200, 1, 2), (96, 40, 2, 3), (1024, 512, 1, 4),
+                                         (2048, 2048, 1, 2)])
+def test_flash_attn(Sq, Skv, B, H):
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Sq + Skv + B + H)
+    q = torch.randn(Sq * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(v, Skv, B, H)
+    # check the re-layout itself, including the zero tail
+    vt_ref = torch.zeros_like(vt)
+    vt_ref[..., :Skv] = v.view(Skv, B, H, 128).permute(1, 2, 3, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(vt, vt_ref), "transpose_v mismatch"
+    out = ops.flash_attn(q, k, vt, Sq, Skv, B, H)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, Sq, Skv, B, H)
+    _report(f"attn {Sq}x{Skv} B{B} H{H}", out, ref)
+    # P is rounded to bf16 before PV (as in flash-attention / TE), output rounded once: ~1e-2 worst-case absolute on O(1) values
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    assert _rel_l2(out, ref) < 1e-2
+
+
+def test_flash_attn_online_softmax_rescale():
+    """A late key with a huge score forces the running-max rescale path (cdna guide rule 26)."""
+    from gen3c_amd import ops
+    dev = _dev()
+    Sq, Skv, B, H = 64, 320, 1, 1
+    g = torch.Generator(device=dev).manual_seed(11)
+    q = torch.randn(Sq, 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(Skv, 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv, 128, device=dev, generator=g).to(torch.bfloat16)
+    k[200] = (q[5].float() * 3.0).to(torch.bfloat16)   # spike for query 5 in the 4th tile
+    k[300] = (q[17].float() * 6.0).to(torch.bfloat16)  # and for query 17 in the 5th
+    vt = ops.transpose_v(v, Skv, B, H)
+    out = ops.flash_attn(q, k, vt, Sq, Skv, B, H)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, Sq, Skv, B, H)
+    _report("attn rescale", out, ref)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_flash_attn_strided_views_and_zero_context_rows():
+    """q/k/v as column views of a fused projection output; zero K/V rows (padded T5 tokens) stay unmasked."""
+    from gen3c_amd import ops
+    dev = _dev()
+    Sq, Skv, B, H = 192, 128, 1, 2
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(3)
+    qkv = torch.randn(Sq, 3 * D, device=dev, generator=g).to(torch.bfloat16)
+    kv = torch.randn(Skv, 2 * D, device=dev, generator=g).to(torch.bfloat16)
+    kv[80:] = 0
+    q, k, v = qkv[:, D:2 * D], kv[:, :D], kv[:, D:]
+    vt = ops.transpose_v(v, Skv, B, H)
+    out = ops.flash_attn(q, k, vt, Sq, Skv, B, H)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), Sq, Skv, B, H)
+    _report("attn strided", out, ref)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,D,B", [(64, 128, 1), (1000, 256, 2), (4096, 4096, 1), (77, 8192, 1)])
+def test_layernorm_modulate(rows, D, B):
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(rows + D)
+    rows = rows // B * B
+    x = (torch.randn(rows, D, device=dev, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    mod = torch.randn(B, 3 * D, device=dev, generator=g).to(torch.bfloat16)
+    shift, scale = mod[:, :D], mod[:, D:2 * D]
+    out = ops.layernorm_modulate(x, shift, scale)
+    torch.cuda.synchronize()
+    xn = torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6)
+    ref = xn * (1 + scale.float().repeat(rows // B, 1)) + shift.float().repeat(rows // B, 1)
+    _report(f"ln_mod {rows}x{D}", out, ref)
+    torch.testing.assert_close(out.float(), ref, rtol=1.0 / 128, atol=1e-2)
+
+
+@pytest.mark.parametrize("S,B,H,rope", [(64, 1, 1, True), (333, 2, 3, True), (512, 1, 32, False)])
+def test_qk_rmsnorm_rope(S, B, H, rope):
+    from gen3c_amd import ops
+    from oracle import dit_oracle
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(S + H)
+    D = H * 128
+    qkv = torch.randn(S * B, 3 * D, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    freqs = torch.randn(S, 128, device=dev, generator=g) * 3
+    x = qkv[:, D:2 * D]
+    cos, sin = (torch.cos(freqs).contiguous(), torch.sin(freqs).contiguous()) if rope else (None, None)
+    out = ops.qk_rmsnorm_rope(x, w, cos, sin, S, B, H)
+    torch.cuda.synchronize()
+    t = x.float().reshape(S, B, H, 128)
+    ref = dit_oracle.te_rmsnorm(t, w.float())
+    if rope:
+        ref = dit_oracle.te_rope_fused(ref, freqs.view(S, 1, 1, 128))
+    ref = ref.reshape(S * B, D)
+    _report(f"qk_norm_rope S{S} B{B} H{H} rope={rope}", out, ref)
+    torch.testing.assert_close(out.float(), ref, rtol=1.5 / 128, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 256, 4096, 1), (1, 12288, 256, 0), (3, 100, 64, 1), (8, 384, 128, 0)])
+def test_gemv(M, N, K, act):
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    add = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    out = ops.gemv(a, w, add=add, act_in=act)
+    torch.cuda.synchronize()
+    af = a.float()
+    if act:
+        af = torch.nn.functional.silu(af).to(torch.bfloat16).float()
+    ref = (af @ w.float().t()).to(torch.bfloat16).float() + add.float()
+    _report(f"gemv {M}x{N}x{K}", out, ref)
+    torch.testing.assert_close(out.float(), ref, rtol=1.5 / 128, atol=2e-2)
+
+
+def test_add_inplace():
+    from gen3c_amd import ops
+    dev = _dev()
+    x = torch.randn(1000, 256, device=dev).to(torch.bfloat16)
+    y = torch.randn(1000, 256, device=dev).to(torch.bfloat16)
+    ref = (x.float() + y.float()).to(torch.bfloat16)
+    ops.add_inplace(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+
+
+def test_errors_are_loud():
+    from gen3c_amd import _lib, ops
+    dev = _dev()
+    a = torch.zeros(8, 12, device=dev, dtype=torch.bfloat16)  # K=12 not a multiple of 8
+    w = torch.zeros(8, 12, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(_lib.Gen3cHipError):
+        ops.gemm_nt(a, w)
+    with pytest.raises(_lib.Gen3cHipError):
+        ops.gemm_nt(a.cpu(), w.cpu())  # no CPU fallback
