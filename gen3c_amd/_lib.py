@@ -50,6 +50,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the HIP runtime of the process BEFORE our library (linked against the
+    # same SONAME) is mapped, otherwise two runtimes coexist and launches fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     if not _LIB_PATH.exists():
         raise Gen3cHipError(
             f"{_LIB_PATH} is missing: build it with `python -m gen3c_amd.build` (or __graft_entry__.build()). "

@@ -46,6 +46,9 @@ G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)
 G3_DEVICE int v_off(int row, int chunk) { return row * KVB + ((chunk ^ ((row >> 1) & 7)) << 3); }  // [128][64]
 G3_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
+// CTX: 0 = long key/value sequence (self-attention), 1 = short context (cross-attention to the 512 T5 tokens).
+// Same code today; separate instantiations so profiles attribute the two very different launches separately.
+template <int CTX>
 __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
@@ -233,12 +236,18 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
-    hipLaunchKernelGGL(flash_attn_fwd_kernel, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    if (Skv > 2048)
+        hipLaunchKernelGGL(flash_attn_fwd_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(flash_attn_fwd_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
     return g3_check_launch("g3_flash_attn_fwd_bf16");
 }
