@@ -18,6 +18,7 @@ vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 SIGNATURES = {
     "g3_last_error": [],
     "g3_abi_version": [],
+    "g3_set_option": [C.c_char_p, i32],
     "g3_device_info": [i32, C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],
     "g3_event_create": [C.POINTER(vp)],
     "g3_event_record": [vp, vp],

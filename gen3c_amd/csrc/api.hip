@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -20,6 +21,20 @@ int g3_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
     return G3_OK;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+int g3_opt_gemm_regstage = env_int("G3_GEMM_REGSTAGE", 0);
+int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 2);
+
+extern "C" int g3_set_option(const char* name, int value) {
+    if (!name) return g3_set_error(G3_ERR_ARG, "g3_set_option: null name");
+    if (!strcmp(name, "gemm_regstage")) { g3_opt_gemm_regstage = value; return G3_OK; }
+    if (!strcmp(name, "attn_variant")) { g3_opt_attn_variant = value; return G3_OK; }
+    return g3_set_error(G3_ERR_ARG, "g3_set_option: unknown option %s", name);
 }
 
 extern "C" const char* g3_last_error(void) { return g_err; }

@@ -23,6 +23,7 @@
 //   * grid = (q_blocks, heads, batch): consecutive workgroups share a head, so all 8 XCD L2s stream the same
 //     K/V^T panels.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -210,6 +211,236 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_kernel(AttnParams 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: software-pipelined variant. Per KV tile t one straight-line region holds
+//        QK^T of tile t+1 (16 MFMA)  ||  exp2 / row-sum / bf16 packing of tile t (VALU)  ->  P.V of tile t (16 MFMA)
+// so the matrix pipe has independent work while the softmax VALU stream runs (the scores of tile t+1 are a second,
+// statically named accumulator set). The row-max + (rare) rescale decision is taken BEFORE that region, on scores that
+// are already complete, with a deferred-rescale threshold: O and l are only rescaled when some row max grew by more
+// than 2^RESCALE_THR since the last rescale (P is then bounded by 2^RESCALE_THR instead of 1 - same relative bf16
+// rounding, fp32 accumulation headroom is ample). K tiles run one tile ahead of V tiles in the LDS ring.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr float RESCALE_THR = 8.0f;
+
+G3_DEVICE float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));  // no canonicalising v_max on MFMA outputs
+    return r;
+}
+// exchange with lane^32: after the swap `a` holds {own low | partner low}, `b` {partner high | own high}
+G3_DEVICE void swap_halves(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+G3_DEVICE float xor32_max(float x) {
+    float a = x, b = x;
+    swap_halves(a, b);
+    return max3(a, b, b);
+}
+G3_DEVICE float xor32_sum(float x) {
+    float a = x, b = x;
+    swap_halves(a, b);
+    return a + b;
+}
+
+template <int CTX>
+__global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
+    bf16_t* sV = sK + 2 * KVB * HD;                     // [2][128][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const int head = blockIdx.y;
+    const int batch = blockIdx.z;
+
+    const bf16_t* Qb = p.Q + batch * p.q_batch + head * p.q_head;
+    const bf16_t* Kb = p.K + batch * p.k_batch + head * p.k_head;
+    const bf16_t* Vb = p.Vt + batch * p.vt_batch + head * p.vt_head;
+    bf16_t* Ob = p.O + batch * p.o_batch + head * p.o_head;
+
+    const int q_idx = blockIdx.x * BQ + wave * QB + l31;
+    const bool q_ok = q_idx < p.Sq;
+    bf16x8 qf[8];
+    {
+        const bf16_t* qrow = Qb + (int64_t)(q_ok ? q_idx : 0) * p.q_row + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = q_ok ? load_bf16x8(qrow + 16 * ks) : zero_bf16x8();
+    }
+
+    bf16x8 rk[2], rv[2];
+    auto load_k = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            const int row = idx >> 4, chunk = idx & 15;
+            rk[i] = (kv0 + row) < p.Skv ? load_bf16x8(Kb + (int64_t)(kv0 + row) * p.k_row + chunk * 8) : zero_bf16x8();
+        }
+    };
+    auto load_v = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            const int row = idx >> 3, chunk = idx & 7;
+            rv[i] = (kv0 + chunk * 8) < p.Skv ? load_bf16x8(Vb + (int64_t)row * p.vt_row + kv0 + chunk * 8) : zero_bf16x8();
+        }
+    };
+    auto write_k = [&](int buf) {
+        bf16_t* dK = sK + buf * KVB * HD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            store_bf16x8(dK + k_off(idx >> 4, idx & 15), rk[i]);
+        }
+    };
+    auto write_v = [&](int buf) {
+        bf16_t* dV = sV + buf * HD * KVB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + NTHREADS * i;
+            store_bf16x8(dV + v_off(idx >> 3, idx & 7), rv[i]);
+        }
+    };
+
+    const int krow_perm = swap23(l31);
+    auto qk = [&](f32x16 (&S)[2], int kbuf) {
+        const bf16_t* cK = sK + kbuf * KVB * HD;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[mb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = load_bf16x8(cK + k_off(32 * mb + krow_perm, 2 * ks + g));
+                S[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[mb], 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 accO[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accO[d][r] = 0.f;
+    float m_run = -1e30f;
+    float l_run = 0.f;
+    const float c = p.scale_log2;
+    const int nt = (p.Skv + KVB - 1) / KVB;
+
+    // ---- prologue: K0, V0 (and K1) resident; S of tile 0 computed
+    load_k(0);
+    load_v(0);
+    write_k(0);
+    write_v(0);
+    if (nt > 1) {
+        load_k(KVB);
+        write_k(1);
+    }
+    __syncthreads();
+    f32x16 SA[2], SB[2];
+    qk(SA, 0);
+
+    // one tile: softmax(S_cur) + PV(t), overlapped with S_next = QK^T(t+1)
+    auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, bool has_next) {
+        const int kv0 = t * KVB;
+        if (kv0 + KVB > p.Skv) {  // ragged last tile
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + 32 * mb + 16 * (r >> 3) + 8 * g + (r & 7);
+                    if (kv >= p.Skv) S_cur[mb][r] = -INFINITY;
+                }
+        }
+        // row max (lane-local chain of v_max3 + one half-swap)
+        float mx = max3(S_cur[0][0], S_cur[0][1], S_cur[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3(mx, S_cur[0][r], S_cur[0][r + 1]);
+        mx = max3(mx, S_cur[0][15], S_cur[1][0]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = max3(mx, S_cur[1][r], S_cur[1][r + 1]);
+        mx = fmaxf(mx, S_cur[1][15]);
+        mx = xor32_max(mx) * c;
+        if (__any(mx - m_run > RESCALE_THR)) {  // wave-uniform, rare after the first tiles
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+        }
+
+        // ---- straight-line region
+        if (has_next) {
+            if (t + 2 < nt) load_k(kv0 + 2 * KVB);
+            load_v(kv0 + KVB);
+            __builtin_amdgcn_s_setprio(1);
+            qk(S_next, (t + 1) & 1);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        const float neg_m = -m_run;
+        float psum = 0.f;
+        bf16x8 pb[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S_cur[mb][r], c, neg_m));
+                psum += pv;
+                pb[2 * mb + (r >> 3)][r & 7] = f32_to_bf16(pv);
+            }
+        l_run += psum;
+        const bf16_t* cV = sV + (t & 1) * HD * KVB;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bf16x8 vf = load_bf16x8(cV + v_off(32 * d + l31, 2 * s + g));
+                accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], accO[d], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (has_next) {
+            if (t + 2 < nt) write_k(t & 1);   // K(t+2) replaces K(t)   (last read in iteration t-1)
+            write_v((t + 1) & 1);             // V(t+1) replaces V(t-1) (last read in iteration t-1)
+            __syncthreads();
+        }
+    };
+
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        tile(SA, SB, t, true);
+        tile(SB, SA, t + 1, true);
+    }
+    if (t + 1 < nt) {  // two tiles left
+        tile(SA, SB, t, true);
+        tile(SB, SA, t + 1, false);
+    } else {           // one tile left
+        tile(SA, SB, t, false);
+    }
+
+    const float l_tot = xor32_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(accO[d][4 * q4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * q4 + 4 * g) = o;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k,
@@ -235,19 +466,24 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
+    const int variant = g3_opt_attn_variant;  // 1 = non-pipelined v1 kernel (kept for A/B measurements), else v2
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        const void* fns[4] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>)};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         attr_set = true;
     }
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
-    if (Skv > 2048)
-        hipLaunchKernelGGL(flash_attn_fwd_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(flash_attn_fwd_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    const bool long_ctx = Skv > 2048;
+    if (variant == 1) {
+        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(flash_attn_fwd_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    } else {
+        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    }
     return g3_check_launch("g3_flash_attn_fwd_bf16");
 }

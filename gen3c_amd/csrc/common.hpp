@@ -24,6 +24,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int g3_set_error(int code, const char* fmt, ...);
 int g3_check_launch(const char* what);
 
+// runtime switches for A/B measurements (g3_set_option); defaults come from the environment on first use
+extern int g3_opt_gemm_regstage;  // 1: register-staged GEMM even when the direct-to-LDS path applies
+extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
+
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }
 G3_DEVICE bf16_t f32_to_bf16(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32 on gfx950)
 

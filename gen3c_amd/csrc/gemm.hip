@@ -18,6 +18,7 @@
 //   * blockIdx is remapped so that the 8 XCDs each own a contiguous band of token tiles (private L2 reuse of
 //     the weight panel).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,7 +43,12 @@ G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] b
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int EPI>
+// STAGE_GLDS = true : tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no staging VGPRs, no ds_write
+//                     pass); the LDS image is lane-linear per wave, so the XOR swizzle is applied to the per-lane
+//                     SOURCE address (same involution as the read side). Needs K % 64 == 0 (no zero-fill on this path;
+//                     M/N tails read a clamped valid row whose results are never stored).
+// STAGE_GLDS = false: global -> VGPR -> ds_write_b128 with zero-fill guards (any K % 8 == 0).
+template <int EPI, bool STAGE_GLDS>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);  // [2][BM][BK]
@@ -103,6 +109,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
             store_bf16x8(dW + lds_off(row, ld_chunk), rw[i]);
         }
     };
+    // direct-to-LDS staging: this lane fills physical slot (row = ld_row + 64 i, chunk = ld_chunk) of the tile, i.e. it
+    // must fetch LOGICAL chunk ld_chunk ^ ((row >> 1) & 7) = ld_chunk ^ ((tid >> 4) & 7)  (64 i does not touch bits 1..3).
+    const int src_chunk = ld_chunk ^ ((tid >> 4) & 7);
+    const bf16_t* ga[4];
+    const bf16_t* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = ld_row + 64 * i;
+        const int ra_row = (m0 + row) < p.M ? (m0 + row) : (p.M - 1);
+        const int rw_row = (n0 + row) < p.N ? (n0 + row) : (p.N - 1);
+        ga[i] = p.A + (int64_t)ra_row * p.lda + src_chunk * 8;
+        gw[i] = p.W + (int64_t)rw_row * p.ldw + src_chunk * 8;
+    }
+    auto stage_glds = [&](int k0, int buf) {
+        bf16_t* dA = sA + buf * BM * BK + wave * 64 * 8;  // wave-uniform base; the hardware adds lane*16 bytes
+        bf16_t* dW = sW + buf * BN * BK + wave * 64 * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(dA + i * 512 * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(dW + i * 512 * 8), 16, 0, 0);
+        }
+    };
 
     // ---- wave tile: 128 features x 64 tokens
     const int wn = wave & 1;
@@ -119,13 +149,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    stage_load(0);
-    stage_write(0);
+    if (STAGE_GLDS) {
+        stage_glds(0, 0);
+    } else {
+        stage_load(0);
+        stage_write(0);
+    }
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nk) stage_load((t + 1) * BK);
+        if (t + 1 < nk) {
+            if (STAGE_GLDS) stage_glds((t + 1) * BK, buf ^ 1);  // buf^1 was last read in iteration t-1 (barrier passed)
+            else stage_load((t + 1) * BK);
+        }
 
         const bf16_t* cA = sA + buf * BM * BK;
         const bf16_t* cW = sW + buf * BN * BK;
@@ -144,8 +181,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
 
-        if (t + 1 < nk) stage_write(buf ^ 1);
-        __syncthreads();
+        if (!STAGE_GLDS && t + 1 < nk) stage_write(buf ^ 1);
+        __syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) here: tile t+1 has landed for every wave
     }
 
     // ---- epilogue. acc[i][j][r]: feature = n_w0+32i + (r&3) + 8*(r>>2) + 4*g ; token = m_w0+32j + l31
@@ -191,19 +228,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
     }
 }
 
-template <int EPI>
-int launch(const GemmParams& p, hipStream_t stream) {
+template <int EPI, bool STAGE_GLDS>
+int launch_variant(const GemmParams& p, hipStream_t stream) {
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);  // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI, STAGE_GLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int nblk = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(nblk), dim3(NTHREADS), smem, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, STAGE_GLDS>), dim3(nblk), dim3(NTHREADS), smem, stream, p);
     return g3_check_launch("g3_gemm_bf16_nt");
+}
+
+template <int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    if ((p.K % BK) == 0 && !g3_opt_gemm_regstage) return launch_variant<EPI, true>(p, stream);
+    return launch_variant<EPI, false>(p, stream);
 }
 
 }  // namespace

@@ -19,6 +19,11 @@ EPI_NONE, EPI_GELU, EPI_GATED_RESIDUAL, EPI_BIAS = 0, 1, 2, 3
 _KERNEL_TIMERS = None
 
 
+def set_option(name: str, value: int):
+    """Runtime A/B switch of the C library (g3_set_option)."""
+    _lib.check(_lib.load().g3_set_option(name.encode(), int(value)), "g3_set_option")
+
+
 def enable_kernel_timers(on: bool = True):
     global _KERNEL_TIMERS
     _KERNEL_TIMERS = [] if on else None

@@ -34,6 +34,8 @@ extern "C" {
 
 const char* g3_last_error(void);
 int g3_abi_version(void);
+/* runtime switches for A/B measurements: "gemm_regstage" (0/1), "attn_variant" (1 = non-pipelined, 2 = pipelined). */
+int g3_set_option(const char* name /*host*/, int value);
 int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name /*host*/, int arch_name_len);
 
 /* hipEvent helpers (opaque handles) so a host can time a stream without linking HIP itself. */

@@ -30,9 +30,13 @@ def _report(name, got, ref):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 260, 136), (1000, 64, 328), (56, 1024, 4096),
                                    (2048, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-def test_gemm_nt(M, N, K, epi):
+@pytest.mark.parametrize("regstage", [0, 1])
+def test_gemm_nt(M, N, K, epi, regstage):
     from gen3c_amd import ops
     dev = _dev()
+    if regstage == 1 and K % 64 != 0:
+        pytest.skip("K % 64 != 0 always takes the register-staged path")
+    ops.set_option("gemm_regstage", regstage)
     g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K + epi)
     a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
@@ -51,7 +55,8 @@ def test_gemm_nt(M, N, K, epi):
     else:
         out = ops.gemm_nt(a, w)
     torch.cuda.synchronize()
-    _report(f"gemm {M}x{N}x{K} epi{epi}", out, ref)
+    ops.set_option("gemm_regstage", 0)
+    _report(f"gemm {M}x{N}x{K} epi{epi} regstage{regstage}", out, ref)
     # one bf16 rounding of the output (2^-8 relative worst case) + fp32 accumulation noise
     torch.testing.assert_close(out.float(), ref, rtol=1.0 / 128, atol=2e-2)
     assert _rel_l2(out, ref) < 4e-3
@@ -81,9 +86,18 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
+@pytest.fixture(params=[1, 2], ids=["attn_v1", "attn_v2"])
+def attn_variant(request):
+    from gen3c_amd import ops
+    ops.set_option("attn_variant", request.param)
+    yield request.param
+    ops.set_option("attn_variant", 2)
+
+
 @pytest.mark.parametrize("Sq,Skv,B,H", [(256, 256, 1, 1), (512, 512, 1, 2), (300, 200, 1, 2), (96, 40, 2, 3), (1024, 512, 1, 4),
-                                         (2048, 2048, 1, 2)])
-def test_flash_attn(Sq, Skv, B, H):
+                                         (2048, 2048, 1, 2), (64, 64, 1, 1), (64, 65, 1, 1), (100, 128, 1, 1), (70, 129, 1, 1),
+                                         (512, 4160, 1, 1)])
+def test_flash_attn(Sq, Skv, B, H, attn_variant):
     from gen3c_amd import ops
     dev = _dev()
     g = torch.Generator(device=dev).manual_seed(Sq + Skv + B + H)
@@ -105,8 +119,9 @@ def test_flash_attn(Sq, Skv, B, H):
     assert _rel_l2(out, ref) < 1e-2
 
 
-def test_flash_attn_online_softmax_rescale():
-    """A late key with a huge score forces the running-max rescale path (cdna guide rule 26)."""
+def test_flash_attn_online_softmax_rescale(attn_variant):
+    """A late key with a huge score forces the running-max rescale path (cdna guide rule 26); moderate growth
+    (< the deferred-rescale threshold of the pipelined kernel) exercises the no-rescale path with P > 1."""
     from gen3c_amd import ops
     dev = _dev()
     Sq, Skv, B, H = 64, 320, 1, 1
@@ -116,6 +131,8 @@ def test_flash_attn_online_softmax_rescale():
     v = torch.randn(Skv, 128, device=dev, generator=g).to(torch.bfloat16)
     k[200] = (q[5].float() * 3.0).to(torch.bfloat16)   # spike for query 5 in the 4th tile
     k[300] = (q[17].float() * 6.0).to(torch.bfloat16)  # and for query 17 in the 5th
+    k[130] = (q[40].float() * 0.5).to(torch.bfloat16)  # score ~ +5.6 (log2 domain ~ +8): around the defer threshold
+    k[131] = (q[41].float() * 0.3).to(torch.bfloat16)  # below the threshold: stays on the deferred path
     vt = ops.transpose_v(v, Skv, B, H)
     out = ops.flash_attn(q, k, vt, Sq, Skv, B, H)
     torch.cuda.synchronize()
@@ -124,7 +141,7 @@ def test_flash_attn_online_softmax_rescale():
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
 
 
-def test_flash_attn_strided_views_and_zero_context_rows():
+def test_flash_attn_strided_views_and_zero_context_rows(attn_variant):
     """q/k/v as column views of a fused projection output; zero K/V rows (padded T5 tokens) stay unmasked."""
     from gen3c_amd import ops
     dev = _dev()
