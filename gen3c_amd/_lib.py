@@ -32,6 +32,12 @@ SIGNATURES = {
     "g3_layernorm_modulate_bf16": [vp, i64, vp, vp, i64, i32, vp, i64, i32, i32, f32, vp],
     "g3_qk_rmsnorm_rope_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
     "g3_add_inplace_bf16": [vp, vp, i64, vp],
+    "g3_warp_project_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "g3_warp_splat_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "g3_warp_resolve_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "g3_mesh_occlusion_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "g3_unproject_points_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "g3_reliable_depth_mask_f32": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "g3_edm_prepare_input_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, vp],
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }

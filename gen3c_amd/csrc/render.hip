@@ -1,0 +1,418 @@
+// 3D-cache renderer: unproject -> project/warp -> bilinear splat -> (optional) mesh-occlusion masking.
+//
+// Replaces, for the GEN3C cache path (cache_3d.py:183-223 -> forward_warp(depth1=None, world_points1=...)):
+//   project_points / forward_warp / bilinear_splatting   forward_warp_utils_pytorch.py:171-336, 462-486, 576-695
+//   points_to_mesh + get_camera_rays                      forward_warp_utils_pytorch.py:49-132, 151-168
+//   ray_triangle_intersection (NVIDIA Warp kernel)        ray_triangle_intersection_warp.py:23-105
+//   unproject_points, reliable_depth_mask_range_batch     forward_warp_utils_pytorch.py:338-353, 410-460
+//
+// The reference runs ~40 elementwise torch kernels + 8 index_put_(accumulate) scatters per splat and a brute-force
+// rays x triangles loop. Here an item (one target frame of one cache buffer) costs three streaming passes:
+//   (1) project: world point -> camera z, flow, validity, per-GROUP max of log1p(z) (the reference takes that max over
+//       every item of one forward_warp call = warp_chunk_size items, so groups reproduce its pairing);
+//   (2) splat:   4 corner weights, 5 fp32 atomics per corner (r, g, b, z, weight) into an [h+2][w+2][5] accumulator;
+//   (3) resolve: normalise, fill, clamp, crop.
+// Mesh occlusion is a conservative rasteriser: each boundary patch (2 triangles of the 4x-downsampled mesh) is
+// projected to its pixel bounding box and ONLY those rays are tested with the same Moller-Trumbore arithmetic the
+// reference applies to every (ray, triangle) pair; min-t is an atomicMin on the float bit pattern, so the result is
+// independent of evaluation order and identical to the brute-force min.
+//
+// Arithmetic: fp32 with the explicit operation order of oracle/warp_oracle.py (the library is built with
+// -ffp-contract=off): pixel indices and masks are bit-exact w.r.t. the oracle; accumulated floats depend on atomic
+// order (as they do in the reference) and on libm's log1p/exp.
+#include "common.hpp"
+
+namespace {
+
+constexpr int ACC_C = 5;  // r, g, b, z, weight
+
+struct Mat { float m[16]; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// (1) project
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_project_kernel(const float* __restrict__ points, const float* __restrict__ w2c,
+                                                           const float* __restrict__ Kmat, const float* __restrict__ mask1,
+                                                           float* __restrict__ zbuf, float* __restrict__ flow,
+                                                           float* __restrict__ cam_out, float* __restrict__ maskz,
+                                                           unsigned* __restrict__ group_max, int n, int h, int w,
+                                                           int group_size) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const float* W = w2c + item * 16;
+    const float* K = Kmat + item * 9;
+    float local_max = 0.f;  // log1p(max(z,0)) >= 0
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const int64_t o = (int64_t)item * hw + pix;
+        const float x = points[o * 3 + 0], y = points[o * 3 + 1], zz = points[o * 3 + 2];
+        float cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
+        float pr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pr[i] = (K[i * 3 + 0] * cam[0] + K[i * 3 + 1] * cam[1]) + K[i * 3 + 2] * cam[2];
+        const float z = pr[2];
+        const float u = pr[0] / (z + 1e-7f);
+        const float v = pr[1] / (z + 1e-7f);
+        const int py = pix / w, px = pix - py * w;
+        flow[((int64_t)item * 2 + 0) * hw + pix] = u - (float)px;
+        flow[((int64_t)item * 2 + 1) * hw + pix] = v - (float)py;
+        zbuf[o] = z;
+        const float m = (mask1 ? mask1[o] : 1.0f) * ((z > 0.f) ? 1.0f : 0.0f);
+        maskz[o] = m;
+        if (cam_out) { cam_out[o * 3 + 0] = cam[0]; cam_out[o * 3 + 1] = cam[1]; cam_out[o * 3 + 2] = cam[2]; }
+        local_max = fmaxf(local_max, log1pf(fmaxf(z, 0.f)));  // NaN z is ignored by fmaxf, as by torch.max? (see header note)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(group_max + item / group_size, __float_as_uint(local_max));  // non-negative floats order like uints
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (2) splat
+// ---------------------------------------------------------------------------------------------------------------
+G3_DEVICE int clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
+
+struct SplatGeom { int fx, cx, fy, cy; float nw, sw, ne, se; };
+
+G3_DEVICE SplatGeom splat_geom(float flow_x, float flow_y, int px, int py, int h, int w) {
+    const float tx = flow_x + (float)px, ty = flow_y + (float)py;  // trans_pos = flow12 + grid
+    const float ox = tx + 1.0f, oy = ty + 1.0f;
+    SplatGeom g;
+    // floor/ceil -> .long() -> clamp; NaN/inf follow the CPU reference (NaN -> INT64_MIN -> clamps to 0)
+    const float flx = floorf(ox), clx = ceilf(ox), fly = floorf(oy), cly = ceilf(oy);
+    auto to_ll = [](float f) -> long long { return (f != f) ? (long long)0x8000000000000000ULL : (f >= 9.2e18f ? 0x7fffffffffffffffLL : (f <= -9.2e18f ? (long long)0x8000000000000000ULL : (long long)f)); };
+    g.fx = clampi(to_ll(flx), 0, w + 1);
+    g.cx = clampi(to_ll(clx), 0, w + 1);
+    g.fy = clampi(to_ll(fly), 0, h + 1);
+    g.cy = clampi(to_ll(cly), 0, h + 1);
+    const float oxc = fminf(fmaxf(ox, 0.f), (float)(w + 1));
+    const float oyc = fminf(fmaxf(oy, 0.f), (float)(h + 1));
+    const float wy_f = 1.0f - (oyc - (float)g.fy);
+    const float wy_c = 1.0f - ((float)g.cy - oyc);
+    const float wx_f = 1.0f - (oxc - (float)g.fx);
+    const float wx_c = 1.0f - ((float)g.cx - oxc);
+    g.nw = wy_f * wx_f; g.sw = wy_c * wx_f; g.ne = wy_f * wx_c; g.se = wy_c * wx_c;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void warp_splat_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
+                                                         const float* __restrict__ flow, const float* __restrict__ maskz,
+                                                         const unsigned* __restrict__ group_max, float* __restrict__ accum,
+                                                         int n, int h, int w, int group_size) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const float lmax = __uint_as_float(group_max[item / group_size]);
+    const int aw = w + 2;
+    float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const int64_t o = (int64_t)item * hw + pix;
+        const float m = maskz[o];
+        if (m == 0.f) continue;  // zero weight: contributes nothing (the reference adds exact zeros)
+        const int py = pix / w, px = pix - py * w;
+        const float z = zbuf[o];
+        const SplatGeom g = splat_geom(flow[((int64_t)item * 2 + 0) * hw + pix], flow[((int64_t)item * 2 + 1) * hw + pix], px, py, h, w);
+        const float logd = log1pf(fmaxf(z, 0.f));
+        const float expo = logd / (lmax + 1e-7f) * 50.0f;
+        const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
+        const float r = image[((int64_t)item * 3 + 0) * hw + pix];
+        const float gc = image[((int64_t)item * 3 + 1) * hw + pix];
+        const float b = image[((int64_t)item * 3 + 2) * hw + pix];
+        const float wts[4] = {g.nw * m * 1.0f / dw, g.sw * m * 1.0f / dw, g.ne * m * 1.0f / dw, g.se * m * 1.0f / dw};
+        const int ys[4] = {g.fy, g.cy, g.fy, g.cy};
+        const int xs[4] = {g.fx, g.fx, g.cx, g.cx};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* a = acc_item + ((int64_t)ys[c] * aw + xs[c]) * ACC_C;
+            const float wt = wts[c];
+            unsafeAtomicAdd(a + 0, r * wt);
+            unsafeAtomicAdd(a + 1, gc * wt);
+            unsafeAtomicAdd(a + 2, b * wt);
+            unsafeAtomicAdd(a + 3, z * wt);
+            unsafeAtomicAdd(a + 4, wt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (3) resolve
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_resolve_kernel(const float* __restrict__ accum, float* __restrict__ frame,
+                                                           float* __restrict__ mask, float* __restrict__ depth, int n,
+                                                           int h, int w) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const int aw = w + 2;
+    const float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const int py = pix / w, px = pix - py * w;
+        const float* a = acc_item + ((int64_t)(py + 1) * aw + (px + 1)) * ACC_C;
+        float wt = a[4];
+        if (wt != wt) wt = 1000.0f;  // nan_to_num(nan=1000)
+        const bool ok = wt > 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = ok ? a[c] / wt : -1.0f;
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+            frame[((int64_t)item * 3 + c) * hw + pix] = v;
+        }
+        mask[(int64_t)item * hw + pix] = ok ? 1.0f : 0.0f;
+        if (depth) depth[(int64_t)item * hw + pix] = ok ? a[3] / wt : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mesh occlusion
+// ---------------------------------------------------------------------------------------------------------------
+G3_DEVICE void bilinear_src(int i, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    float c = ((float)i + 0.5f) * scale - 0.5f;
+    c = fmaxf(c, 0.f);
+    i0 = (int)floorf(c);
+    i1 = min(i0 + 1, n_in - 1);
+    l1 = c - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __restrict__ cam, const uint8_t* __restrict__ bmask,
+                                                              float* __restrict__ pts, uint8_t* __restrict__ m, int n, int h,
+                                                              int w, int nh, int nw) {
+    const int item = blockIdx.y;
+    const float sy = (float)h / (float)nh, sx = (float)w / (float)nw;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nh * nw; idx += gridDim.x * 256) {
+        const int i = idx / nw, j = idx - i * nw;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        bilinear_src(i, sy, h, y0, y1, wy0, wy1);
+        bilinear_src(j, sx, w, x0, x1, wx0, wx1);
+        const float* c = cam + (int64_t)item * h * w * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float top = c[((int64_t)y0 * w + x0) * 3 + k] * wx0 + c[((int64_t)y0 * w + x1) * 3 + k] * wx1;
+            const float bot = c[((int64_t)y1 * w + x0) * 3 + k] * wx0 + c[((int64_t)y1 * w + x1) * 3 + k] * wx1;
+            pts[((int64_t)item * nh * nw + idx) * 3 + k] = top * wy0 + bot * wy1;
+        }
+        const int my = (int)floorf((float)i * sy), mx = (int)floorf((float)j * sx);
+        m[(int64_t)item * nh * nw + idx] = bmask[(int64_t)item * h * w + (int64_t)my * w + mx] ? 1 : 0;
+    }
+}
+
+struct V3 { float x, y, z; };
+G3_DEVICE V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+G3_DEVICE V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+G3_DEVICE float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+G3_DEVICE V3 pixel_ray(const float* Ki, int px, int py) {  // get_camera_rays: K^-1 [x,y,1], normalised
+    const float xs = (float)px, ys = (float)py;
+    V3 d;
+    d.x = (Ki[0] * xs + Ki[1] * ys) + Ki[2] * 1.0f;
+    d.y = (Ki[3] * xs + Ki[4] * ys) + Ki[5] * 1.0f;
+    d.z = (Ki[6] * xs + Ki[7] * ys) + Ki[8] * 1.0f;
+    float nrm = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+    if (nrm == 0.f) nrm = 1.f;
+    return {d.x / nrm, d.y / nrm, d.z / nrm};
+}
+
+// one wave per mesh patch; lanes sweep the pixel bounding box of each of its two triangles
+__global__ __launch_bounds__(256) void mesh_raster_kernel(const float* __restrict__ pts, const uint8_t* __restrict__ m,
+                                                          const float* __restrict__ Kmat, const float* __restrict__ Kinv,
+                                                          unsigned* __restrict__ tmin, int n, int h, int w, int nh, int nw,
+                                                          float eps) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int patch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int npatch = (nh - 1) * (nw - 1);
+    if (patch >= npatch) return;
+    const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
+    const uint8_t* mi = m + (int64_t)item * nh * nw;
+    if (!(mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1])) return;
+    const float* P = pts + (int64_t)item * nh * nw * 3;
+    auto vert = [&](int i, int j) -> V3 { const float* p = P + ((int64_t)i * nw + j) * 3; return {p[0], p[1], p[2]}; };
+    const V3 tl = vert(pi, pj), tr = vert(pi, pj + 1), bl = vert(pi + 1, pj), br = vert(pi + 1, pj + 1);
+    const float* K = Kmat + item * 9;
+    const float* Ki = Kinv + item * 9;
+    unsigned* out = tmin + (int64_t)item * h * w;
+    for (int tri = 0; tri < 2; ++tri) {
+        const V3 v0 = tri == 0 ? tl : tr, v1 = tri == 0 ? tr : br, v2 = bl;
+        // conservative pixel bounding box of the projected triangle (whole image if it touches the camera plane)
+        int x_lo = 0, x_hi = w - 1, y_lo = 0, y_hi = h - 1;
+        if (v0.z > 1e-4f && v1.z > 1e-4f && v2.z > 1e-4f) {
+            float minx = 3e38f, maxx = -3e38f, miny = 3e38f, maxy = -3e38f;
+            const V3 vs[3] = {v0, v1, v2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float X = (K[0] * vs[k].x + K[1] * vs[k].y + K[2] * vs[k].z) / vs[k].z;
+                const float Y = (K[3] * vs[k].x + K[4] * vs[k].y + K[5] * vs[k].z) / vs[k].z;
+                minx = fminf(minx, X); maxx = fmaxf(maxx, X); miny = fminf(miny, Y); maxy = fmaxf(maxy, Y);
+            }
+            if (!(maxx >= -2.f && minx <= (float)w + 1.f && maxy >= -2.f && miny <= (float)h + 1.f)) continue;  // off-screen
+            x_lo = max(0, (int)floorf(fmaxf(minx, -2.f)) - 1);
+            y_lo = max(0, (int)floorf(fmaxf(miny, -2.f)) - 1);
+            x_hi = min(w - 1, (int)ceilf(fminf(maxx, (float)w + 1.f)) + 1);
+            y_hi = min(h - 1, (int)ceilf(fminf(maxy, (float)h + 1.f)) + 1);
+            if (x_hi < x_lo || y_hi < y_lo) continue;
+        }
+        const V3 e1 = sub(v1, v0), e2 = sub(v2, v0);
+        const V3 s = {0.f - v0.x, 0.f - v0.y, 0.f - v0.z};  // ray origin (0) - v0
+        const V3 q = cross(s, e1);
+        const float e2q = dot(e2, q);
+        const int bw = x_hi - x_lo + 1;
+        const int npix = bw * (y_hi - y_lo + 1);
+        for (int k = lane; k < npix; k += 64) {
+            const int py = y_lo + k / bw, px = x_lo + k % bw;
+            const V3 d = pixel_ray(Ki, px, py);
+            const V3 hh = cross(d, e2);
+            const float a = dot(e1, hh);
+            if (fabsf(a) < eps) continue;
+            const float f = 1.0f / a;
+            const float u = f * dot(s, hh);
+            if (u < 0.f || u > 1.f) continue;
+            const float v = f * dot(d, q);
+            if (v < 0.f || (u + v) > 1.f) continue;
+            const float t = f * e2q;
+            if (t > eps) atomicMin(out + (int64_t)py * w + px, __float_as_uint(t));  // t > 0: uint order == float order
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mesh_apply_kernel(const unsigned* __restrict__ tmin, const float* __restrict__ Kinv,
+                                                         float* __restrict__ frame, float* __restrict__ mask,
+                                                         float* __restrict__ depth, int n, int h, int w) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const float* Ki = Kinv + item * 9;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const unsigned bits = tmin[(int64_t)item * hw + pix];
+        const float t = (bits == 0x7f800000u) ? 0.f : __uint_as_float(bits);
+        const int py = pix / w, px = pix - py * w;
+        const V3 d = pixel_ray(Ki, px, py);
+        const float mesh_z = t * d.z;
+        const int64_t o = (int64_t)item * hw + pix;
+        const bool closer = ((mesh_z + 0.02f) < depth[o]) && (mesh_z > 0.f);
+        const float keep = closer ? 0.f : 1.f;
+        mask[o] = mask[o] * keep;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t oc = ((int64_t)item * 3 + c) * hw + pix;
+            frame[oc] = (frame[oc] + 1.0f) * keep - 1.0f;
+        }
+        depth[o] = depth[o] * keep;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cache construction helpers
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict__ depth, const float* __restrict__ c2w,
+                                                        const float* __restrict__ Kinv, float* __restrict__ points, int n,
+                                                        int h, int w) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const float* Ki = Kinv + item * 9;
+    const float* C = c2w + item * 16;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const int py = pix / w, px = pix - py * w;
+        const float d = depth[(int64_t)item * hw + pix];
+        const float xs = (float)px, ys = (float)py;
+        float un[3], camp[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            un[r] = (Ki[r * 3 + 0] * xs + Ki[r * 3 + 1] * ys) + Ki[r * 3 + 2] * 1.0f;
+            camp[r] = d * un[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float val = ((C[r * 4 + 0] * camp[0] + C[r * 4 + 1] * camp[1]) + C[r * 4 + 2] * camp[2]) + C[r * 4 + 3] * 1.0f;
+            points[((int64_t)item * hw + pix) * 3 + r] = (d > 0.f) ? val : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reliable_mask_kernel(const float* __restrict__ depth, uint8_t* __restrict__ out, int n,
+                                                            int h, int w, int window, float thr, float eps) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const int r = window / 2;
+    const float* d = depth + (int64_t)item * hw;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
+        const int py = pix / w, px = pix - py * w;
+        float mx = -INFINITY, mn = INFINITY, sm = 0.f;
+        for (int dy = -r; dy <= r; ++dy)
+            for (int dx = -r; dx <= r; ++dx) {  // same accumulation order as the oracle: row-major over the window
+                const int y = py + dy, x = px + dx;
+                const bool in = (y >= 0 && y < h && x >= 0 && x < w);
+                const float v = in ? d[y * w + x] : 0.f;
+                if (in) { mx = fmaxf(mx, v); mn = fminf(mn, v); }
+                sm = sm + v;
+            }
+        const float mean = sm / (float)(window * window);
+        const float ratio = (mx - mn) / (mean + eps);
+        out[(int64_t)item * hw + pix] = ((ratio < thr) && (d[pix] > 0.f)) ? 1 : 0;
+    }
+}
+
+int grid_x(int work) {
+    int g = (work + 255) / 256;
+    return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int g3_warp_project_f32(const float* points, const float* w2c, const float* K, const float* mask1, float* z,
+                                   float* flow, float* cam_points, float* maskz, void* group_max, int n, int h, int w,
+                                   int group_size, void* stream) {
+    if (!points || !w2c || !K || !z || !flow || !maskz || !group_max) return g3_set_error(G3_ERR_ARG, "g3_warp_project_f32: null operand");
+    if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_project_f32: bad shape");
+    hipLaunchKernelGGL(warp_project_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, points, w2c, K, mask1, z,
+                       flow, cam_points, maskz, (unsigned*)group_max, n, h, w, group_size);
+    return g3_check_launch("g3_warp_project_f32");
+}
+
+extern "C" int g3_warp_splat_f32(const float* image, const float* z, const float* flow, const float* maskz,
+                                 const void* group_max, float* accum, int n, int h, int w, int group_size, void* stream) {
+    if (!image || !z || !flow || !maskz || !group_max || !accum) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_f32: null operand");
+    if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_f32: bad shape");
+    hipLaunchKernelGGL(warp_splat_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, image, z, flow, maskz,
+                       (const unsigned*)group_max, accum, n, h, w, group_size);
+    return g3_check_launch("g3_warp_splat_f32");
+}
+
+extern "C" int g3_warp_resolve_f32(const float* accum, float* frame, float* mask, float* depth, int n, int h, int w,
+                                   void* stream) {
+    if (!accum || !frame || !mask) return g3_set_error(G3_ERR_ARG, "g3_warp_resolve_f32: null operand");
+    if (n <= 0 || h <= 0 || w <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_resolve_f32: bad shape");
+    hipLaunchKernelGGL(warp_resolve_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, accum, frame, mask, depth, n, h, w);
+    return g3_check_launch("g3_warp_resolve_f32");
+}
+
+extern "C" int g3_mesh_occlusion_f32(const float* cam_points, const uint8_t* boundary_mask, const float* K, const float* Kinv,
+                                     float* pts_ds, uint8_t* mask_ds, void* tmin, float* frame, float* mask, float* depth,
+                                     int n, int h, int w, int factor, void* stream) {
+    if (!cam_points || !boundary_mask || !K || !Kinv || !pts_ds || !mask_ds || !tmin || !frame || !mask || !depth)
+        return g3_set_error(G3_ERR_ARG, "g3_mesh_occlusion_f32: null operand");
+    if (n <= 0 || factor <= 0 || h / factor < 2 || w / factor < 2) return g3_set_error(G3_ERR_ARG, "g3_mesh_occlusion_f32: bad shape");
+    const int nh = h / factor, nw = w / factor;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)tmin, 0x7f800000, (size_t)n * h * w, s);  // +inf bit pattern
+    if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_mesh_occlusion_f32: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, cam_points, boundary_mask, pts_ds, mask_ds, n, h, w, nh, nw);
+    const int npatch = (nh - 1) * (nw - 1);
+    hipLaunchKernelGGL(mesh_raster_kernel, dim3((npatch + 3) / 4, n), dim3(256), 0, s, pts_ds, mask_ds, K, Kinv, (unsigned*)tmin, n, h, w, nh, nw, 1e-8f);
+    hipLaunchKernelGGL(mesh_apply_kernel, dim3(grid_x(h * w), n), dim3(256), 0, s, (const unsigned*)tmin, Kinv, frame, mask, depth, n, h, w);
+    return g3_check_launch("g3_mesh_occlusion_f32");
+}
+
+extern "C" int g3_unproject_points_f32(const float* depth, const float* c2w, const float* Kinv, float* points, int n, int h,
+                                       int w, void* stream) {
+    if (!depth || !c2w || !Kinv || !points) return g3_set_error(G3_ERR_ARG, "g3_unproject_points_f32: null operand");
+    if (n <= 0 || h <= 0 || w <= 0) return g3_set_error(G3_ERR_ARG, "g3_unproject_points_f32: bad shape");
+    hipLaunchKernelGGL(unproject_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, depth, c2w, Kinv, points, n, h, w);
+    return g3_check_launch("g3_unproject_points_f32");
+}
+
+extern "C" int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int n, int h, int w, int window, float ratio_thresh,
+                                          float eps, void* stream) {
+    if (!depth || !out) return g3_set_error(G3_ERR_ARG, "g3_reliable_depth_mask_f32: null operand");
+    if (n <= 0 || h <= 0 || w <= 0 || window <= 0 || (window & 1) == 0) return g3_set_error(G3_ERR_ARG, "g3_reliable_depth_mask_f32: window must be odd");
+    hipLaunchKernelGGL(reliable_mask_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, depth, out, n, h, w, window, ratio_thresh, eps);
+    return g3_check_launch("g3_reliable_depth_mask_f32");
+}

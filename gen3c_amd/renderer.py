@@ -1,0 +1,283 @@
+"""MI355X renderer of the GEN3C 3D cache: same Python surface as the reference's
+`forward_warp`, `unproject_points`, `reliable_depth_mask_range_batch` (forward_warp_utils_pytorch.py:171-187, 338-353,
+410-460) and `Cache3D_Base / Cache3D_Buffer` (cache_3d.py:26-343), driving the HIP kernels of csrc/render.hip.
+
+Differences in mechanics, not in results:
+  * the cache (images, world points, masks) lives in HBM for its whole life - the reference keeps it on the CPU and
+    pays an H2D copy + `torch.cuda.empty_cache()` for every 2 items (cache_3d.py:183-223);
+  * all 121*N (frame, buffer) items of a render are processed in large batches; the reference's per-call coupling
+    (log-depth max over the warp_chunk_size=2 items of one forward_warp call) is reproduced with `group_size=2`;
+  * 4x4 / 3x3 inverses are taken on the host in fp32 (LAPACK, like the reference's torch.linalg.inv on CPU tensors).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], name: str, dtype=f32) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise _lib.Gen3cHipError(f"{name}: expected a GPU (HIP) tensor, got {t.device}; the renderer has no CPU path")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.Gen3cHipError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _host_inverse(m: torch.Tensor) -> torch.Tensor:
+    """inverse_with_conversion (forward_warp_utils_pytorch.py:147-148) on the host, result back on m's device."""
+    return torch.linalg.inv(m.detach().to("cpu", f32)).to(m.device)
+
+
+def unproject_points(depth: torch.Tensor, w2c: torch.Tensor, intrinsic: torch.Tensor, is_depth: bool = True,
+                     mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(b,1,h,w) depth -> (b,h,w,3) world points, zeros where depth <= 0 (forward_warp_utils_pytorch.py:410-460)."""
+    if not is_depth or mask is not None:
+        raise NotImplementedError("only is_depth=True with the default mask (depth > 0) is used by the GEN3C cache")
+    b, _, h, w = depth.shape
+    d = depth.to(f32).reshape(b, h, w).contiguous()
+    c2w = _host_inverse(w2c.reshape(b, 4, 4)).contiguous()
+    kinv = _host_inverse(intrinsic.reshape(b, 3, 3)).contiguous()
+    out = torch.empty((b, h, w, 3), dtype=f32, device=depth.device)
+    lib = _lib.load()
+    _lib.check(lib.g3_unproject_points_f32(_p(d, "depth"), _p(c2w, "c2w"), _p(kinv, "Kinv"), _p(out, "points"), b, h, w, _stream()),
+               "g3_unproject_points_f32")
+    return out
+
+
+def reliable_depth_mask_range_batch(depth: torch.Tensor, window_size: int = 5, ratio_thresh: float = 0.05,
+                                    eps: float = 1e-6) -> torch.Tensor:
+    """-> bool (b,1,h,w): (local max - local min) / (local mean + eps) < thr and depth > 0 (:338-353)."""
+    assert window_size % 2 == 1, "Window size must be odd."
+    d4 = depth.unsqueeze(1) if depth.dim() == 3 else depth
+    b, _, h, w = d4.shape
+    d = d4.to(f32).reshape(b, h, w).contiguous()
+    out = torch.empty((b, h, w), dtype=torch.uint8, device=depth.device)
+    lib = _lib.load()
+    _lib.check(lib.g3_reliable_depth_mask_f32(_p(d, "depth"), _p(out, "out", torch.uint8), b, h, w, window_size, ratio_thresh, eps,
+                                              _stream()), "g3_reliable_depth_mask_f32")
+    return out.bool().reshape(b, 1, h, w)
+
+
+def forward_warp(
+    frame1: torch.Tensor,
+    mask1: Optional[torch.Tensor],
+    depth1: Optional[torch.Tensor],
+    transformation1: Optional[torch.Tensor],
+    transformation2: torch.Tensor,
+    intrinsic1: Optional[torch.Tensor],
+    intrinsic2: Optional[torch.Tensor],
+    is_image=True,
+    conditioned_normal1=None,
+    cameraray_filtering=False,
+    is_depth=True,
+    render_depth=False,
+    world_points1=None,
+    foreground_masking=False,
+    boundary_mask=None,
+    group_size: Optional[int] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
+    """Same contract as the reference (forward_warp_utils_pytorch.py:171-336) for the cache path: `depth1=None`,
+    `world_points1` (b,h,w,3) given. Returns (warped_frame2 (b,3,h,w), mask2 (b,1,h,w), warped_depth2 (b,h,w) or None,
+    flow12 (b,2,h,w)). `group_size` (default: the whole batch, i.e. one reference call) sets which items share the
+    log-depth maximum of the splat weights."""
+    if depth1 is not None or conditioned_normal1 is not None or cameraray_filtering or not is_image:
+        raise NotImplementedError("HIP forward_warp implements the GEN3C cache path (depth1=None, world_points1 given, images)")
+    b, c, h, w = frame1.shape
+    assert c == 3 and world_points1.shape == (b, h, w, 3)
+    if intrinsic2 is None:
+        assert intrinsic1 is not None, "intrinsic2 cannot be derived if intrinsic1 is None and intrinsic2 is None"
+        intrinsic2 = intrinsic1
+    dev = frame1.device
+    gs = b if group_size is None else group_size
+    img = frame1.to(f32).contiguous()
+    pts = world_points1.to(f32).contiguous()
+    w2c = transformation2.to(f32).reshape(b, 16).contiguous()
+    K = intrinsic2.to(f32).reshape(b, 9).contiguous()
+    m1 = None if mask1 is None else mask1.to(f32).reshape(b, h, w).contiguous()
+    need_depth = bool(render_depth or foreground_masking)
+
+    z = torch.empty((b, h, w), dtype=f32, device=dev)
+    flow = torch.empty((b, 2, h, w), dtype=f32, device=dev)
+    maskz = torch.empty((b, h, w), dtype=f32, device=dev)
+    cam = torch.empty((b, h, w, 3), dtype=f32, device=dev) if foreground_masking else None
+    ngroups = (b + gs - 1) // gs
+    gmax = torch.zeros((ngroups,), dtype=torch.int32, device=dev)
+    accum = torch.zeros((b, h + 2, w + 2, 5), dtype=f32, device=dev)
+    frame = torch.empty((b, 3, h, w), dtype=f32, device=dev)
+    mask2 = torch.empty((b, h, w), dtype=f32, device=dev)
+    depth2 = torch.empty((b, h, w), dtype=f32, device=dev) if need_depth else None
+
+    lib = _lib.load()
+    st = _stream()
+    _lib.check(lib.g3_warp_project_f32(_p(pts, "points"), _p(w2c, "w2c"), _p(K, "K"), _p(m1, "mask1"), _p(z, "z"), _p(flow, "flow"),
+                                       _p(cam, "cam"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32), b, h, w, gs, st),
+               "g3_warp_project_f32")
+    _lib.check(lib.g3_warp_splat_f32(_p(img, "image"), _p(z, "z"), _p(flow, "flow"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32),
+                                     _p(accum, "accum"), b, h, w, gs, st), "g3_warp_splat_f32")
+    _lib.check(lib.g3_warp_resolve_f32(_p(accum, "accum"), _p(frame, "frame"), _p(mask2, "mask"), _p(depth2, "depth"), b, h, w, st),
+               "g3_warp_resolve_f32")
+    if foreground_masking:
+        assert boundary_mask is not None
+        bm = boundary_mask.reshape(b, h, w).to(torch.uint8).contiguous()
+        kinv = _host_inverse(intrinsic2.reshape(b, 3, 3)).reshape(b, 9).contiguous()
+        factor = 4  # mesh_downsample_factor (forward_warp_utils_pytorch.py:290)
+        nh, nw = h // factor, w // factor
+        pts_ds = torch.empty((b, nh, nw, 3), dtype=f32, device=dev)
+        m_ds = torch.empty((b, nh, nw), dtype=torch.uint8, device=dev)
+        tmin = torch.empty((b, h, w), dtype=torch.int32, device=dev)
+        _lib.check(lib.g3_mesh_occlusion_f32(_p(cam, "cam"), _p(bm, "boundary", torch.uint8), _p(K, "K"), _p(kinv, "Kinv"),
+                                             _p(pts_ds, "pts_ds"), _p(m_ds, "m_ds", torch.uint8), _p(tmin, "tmin", torch.int32),
+                                             _p(frame, "frame"), _p(mask2, "mask"), _p(depth2, "depth"), b, h, w, factor, st),
+                   "g3_mesh_occlusion_f32")
+    out_dtype = frame1.dtype
+    return (frame.to(out_dtype), mask2.reshape(b, 1, h, w).to(out_dtype), None if depth2 is None else depth2.to(out_dtype),
+            flow.to(out_dtype))
+
+
+class Cache3D_Base:
+    """GPU-resident 3D cache with the reference's constructor keywords (cache_3d.py:26-134) for the layouts GEN3C
+    uses: `input_format` a permutation/subset of B,F,N,V,C,H,W with V == 1."""
+
+    def __init__(self, input_image, input_depth, input_w2c, input_intrinsics, input_mask=None, input_format=None,
+                 input_points=None, weight_dtype=torch.float32, is_depth=True, device="cuda", filter_points_threshold=1.0,
+                 foreground_masking=False):
+        if weight_dtype != torch.float32:
+            raise NotImplementedError("the HIP renderer computes in fp32 (the reference's default weight_dtype)")
+        self.weight_dtype, self.is_depth, self.device = weight_dtype, is_depth, torch.device(device)
+        self.filter_points_threshold, self.foreground_masking = filter_points_threshold, foreground_masking
+        if input_format is None:
+            assert input_image.dim() == 4
+            input_format = ["B", "C", "H", "W"]
+        pos = {d: i for i, d in enumerate(input_format)}
+        shape = input_image.shape
+        dim = lambda k: shape[pos[k]] if k in pos else 1
+        B, F, N, V, H, W = dim("B"), dim("F"), dim("N"), dim("V"), dim("H"), dim("W")
+        if V != 1:
+            raise NotImplementedError("multi-view aggregation (V > 1) is not implemented by the reference either (cache_3d.py:229-230)")
+
+        def canon(t, channels):  # -> (B,F,N,V,C,H,W)
+            order = [pos[d] for d in ("B", "F", "N", "V", "C", "H", "W") if d in pos]
+            t = t.permute(*order)
+            for i, d in enumerate(("B", "F", "N", "V", "C", "H", "W")):
+                if d not in pos:
+                    t = t.unsqueeze(i)
+            return t
+
+        self.input_image = canon(input_image, 3).to(self.device, f32).contiguous()
+        self.input_mask = None if input_mask is None else canon(input_mask, 1).to(self.device, f32).contiguous()
+        if input_points is not None:
+            self.input_points = input_points.reshape(B, F, N, V, H, W, 3).to(self.device, f32).contiguous()
+            self.input_depth = None
+        else:
+            d = torch.nan_to_num(input_depth.to(self.device, f32), nan=100)
+            d = torch.clamp(d, min=0, max=100)
+            self.input_points = unproject_points(d.reshape(-1, 1, H, W), input_w2c.reshape(-1, 4, 4).to(self.device),
+                                                 input_intrinsics.reshape(-1, 3, 3).to(self.device)).reshape(B, F, N, V, H, W, 3)
+            self.input_depth = d
+            input_depth = d
+        if self.filter_points_threshold < 1.0 and input_depth is not None:
+            dm = reliable_depth_mask_range_batch(input_depth.reshape(-1, 1, H, W), ratio_thresh=self.filter_points_threshold)
+            dm = dm.reshape(B, F, N, V, 1, H, W).to(f32)
+            self.input_mask = dm if self.input_mask is None else self.input_mask * dm
+        self.boundary_mask = None
+        if foreground_masking:
+            dm = reliable_depth_mask_range_batch(input_depth.reshape(-1, 1, H, W))
+            self.boundary_mask = (~dm).reshape(B, F, N, V, 1, H, W)
+
+    def input_frame_count(self) -> int:
+        return self.input_image.shape[1]
+
+    def update_cache(self):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def render_cache(self, target_w2cs, target_intrinsics, render_depth=False, start_frame_idx=0, items_per_launch: int = 32):
+        """(B,F_t,4,4), (B,F_t,3,3) -> pixels (B,F_t,N,3,H,W) [or depth (B,F_t,N,H,W)], masks (B,F_t,N,1,H,W)
+        (cache_3d.py:151-236). Items are flattened as (B F N) and warped in groups of warp_chunk_size = 2."""
+        bs, Ft = target_w2cs.shape[:2]
+        B, F, N, V, C, H, W = self.input_image.shape
+        assert bs == B
+        sl = slice(start_frame_idx, start_frame_idx + Ft)
+        ex = lambda t, tail: t[:, sl].expand(B, Ft, N, V, *tail).reshape(B * Ft * N, *tail)
+        imgs = ex(self.input_image, (C, H, W))
+        pts = ex(self.input_points, (H, W, 3))
+        msk = None if self.input_mask is None else ex(self.input_mask, (1, H, W))
+        bnd = None if self.boundary_mask is None else self.boundary_mask.expand(B, Ft, N, V, 1, H, W).reshape(B * Ft * N, H, W)
+        w2cs = target_w2cs.to(self.device, f32).reshape(B, Ft, 1, 4, 4).expand(B, Ft, N, 4, 4).reshape(-1, 4, 4)
+        Ks = target_intrinsics.to(self.device, f32).reshape(B, Ft, 1, 3, 3).expand(B, Ft, N, 3, 3).reshape(-1, 3, 3)
+        n = imgs.shape[0]
+        step = max(2, items_per_launch // 2 * 2)  # never split a reference pair
+        frames, masks, depths = [], [], []
+        for i in range(0, n, step):
+            s = slice(i, min(i + step, n))
+            fr, mk, dp, _ = forward_warp(imgs[s], None if msk is None else msk[s], None, None, w2cs[s], Ks[s], Ks[s],
+                                         render_depth=render_depth, world_points1=pts[s],
+                                         foreground_masking=self.foreground_masking,
+                                         boundary_mask=None if bnd is None else bnd[s], group_size=2)
+            frames.append(fr)
+            masks.append(mk)
+            if render_depth:
+                depths.append(dp)
+        masks = torch.cat(masks).reshape(bs, Ft, N, 1, H, W)
+        if render_depth:
+            return torch.cat(depths).reshape(bs, Ft, N, H, W), masks
+        return torch.cat(frames).reshape(bs, Ft, N, 3, H, W), masks
+
+
+class Cache3D_Buffer(Cache3D_Base):
+    """cache_3d.py:239-343: newest-first frame buffer of at most `frame_buffer_max` entries + per-buffer noise."""
+
+    def __init__(self, frame_buffer_max=0, noise_aug_strength=0, generator=None, **kwargs):
+        super().__init__(**kwargs)
+        self.frame_buffer_max, self.noise_aug_strength, self.generator = frame_buffer_max, noise_aug_strength, generator
+
+    @torch.no_grad()
+    def update_cache(self, new_image, new_depth, new_w2c, new_mask=None, new_intrinsics=None, depth_alignment=True,
+                     alignment_method="non_rigid"):
+        if depth_alignment:
+            raise NotImplementedError("depth alignment (camera_utils.align_depth) is the autoregressive row (SURVEY 8f-1), not built yet")
+        new_image = new_image.to(self.device, f32)
+        new_depth = torch.clamp(torch.nan_to_num(new_depth.to(self.device, f32), nan=1e4), min=0, max=1e4)
+        new_points = unproject_points(new_depth, new_w2c.to(self.device, f32), new_intrinsics.to(self.device, f32))
+        B, F, N, V, C, H, W = self.input_image.shape
+        if self.filter_points_threshold < 1.0:
+            dm = reliable_depth_mask_range_batch(new_depth.reshape(-1, 1, H, W), ratio_thresh=self.filter_points_threshold)
+            dm = dm.reshape(B, 1, H, W).to(f32)
+            new_mask = dm if new_mask is None else new_mask.to(self.device, f32) * dm
+        if self.frame_buffer_max > 1:
+            if N < self.frame_buffer_max:
+                self.input_image = torch.cat([new_image[:, None, None, None], self.input_image], 2)
+                self.input_points = torch.cat([new_points[:, None, None, None], self.input_points], 2)
+                if self.input_mask is not None:
+                    self.input_mask = torch.cat([new_mask[:, None, None, None], self.input_mask], 2)
+            else:
+                self.input_image[:, :, 0] = new_image[:, None, None]
+                self.input_points[:, :, 0] = new_points[:, None, None]
+                if self.input_mask is not None:
+                    self.input_mask[:, :, 0] = new_mask[:, None, None]
+        else:
+            self.input_image = new_image[:, None, None, None]
+            self.input_points = new_points[:, None, None, None]
+
+    @torch.no_grad()
+    def render_cache(self, target_w2cs, target_intrinsics, render_depth: bool = False, start_frame_idx: int = 0):
+        assert start_frame_idx == 0, "start_frame_idx must be 0 for Cache3D_Buffer"
+        out_dev = target_w2cs.device
+        pixels, masks = super().render_cache(target_w2cs, target_intrinsics, render_depth)
+        pixels, masks = pixels.to(out_dev), masks.to(out_dev)
+        if not render_depth and self.noise_aug_strength:
+            noise = torch.randn(pixels.shape, generator=self.generator, device=pixels.device, dtype=pixels.dtype)
+            per_buffer = torch.arange(pixels.shape[2] - 1, -1, -1, device=pixels.device) * self.noise_aug_strength
+            pixels = pixels + noise * per_buffer.reshape(1, 1, -1, 1, 1, 1)
+        return pixels, masks

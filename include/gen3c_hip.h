@@ -102,6 +102,34 @@ int g3_edm_cfg_euler_step_bf16(const void* out_cond, const void* out_uncond, con
                                float c_skip_bf16, float c_out_bf16, float c_skip, float c_out, float sigma,
                                float sigma_next, void* stream);
 
+/* ---- 3D-cache renderer (all f32; n "items" = (target frame, cache buffer) pairs, each h x w) -----------------------
+ * Replaces forward_warp(depth1=None, world_points1=...) + bilinear_splatting + the mesh-occlusion branch
+ * (cosmos_predict1/diffusion/inference/forward_warp_utils_pytorch.py:171-336, 462-486, 576-695, 49-132) and the NVIDIA
+ * Warp ray/triangle kernel (ray_triangle_intersection_warp.py:23-105).
+ * The reference takes max(log1p(z)) over every item of one forward_warp call (warp_chunk_size = 2 items,
+ * cache_3d.py:183); `group_size` reproduces that grouping: item i belongs to group i / group_size.
+ *   project : points [n][h][w][3], w2c [n][16], K [n][9], mask1 [n][h][w] or NULL ->
+ *             z [n][h][w], flow [n][2][h][w] (= forward_warp's flow12), cam_points [n][h][w][3] or NULL,
+ *             maskz = mask1*(z>0) [n][h][w], group_max [ceil(n/group_size)] u32 (float bits; ZERO it before the call)
+ *   splat   : accumulates (r,g,b,z,weight) into accum [n][h+2][w+2][5] (ZERO it before the call)
+ *   resolve : frame [n][3][h][w] (fill -1, clamp [-1,1]), mask [n][h][w], depth [n][h][w] or NULL (fill 0)
+ *   mesh_occlusion: boundary_mask [n][h][w] u8, Kinv [n][9]; scratch pts_ds [n][h/f][w/f][3], mask_ds [n][h/f][w/f] u8,
+ *             tmin [n][h][w] u32; zeroes mask/depth and sets frame to -1 where the boundary mesh is closer by > 0.02. */
+int g3_warp_project_f32(const float* points, const float* w2c, const float* K, const float* mask1, float* z, float* flow,
+                        float* cam_points, float* maskz, void* group_max, int n, int h, int w, int group_size, void* stream);
+int g3_warp_splat_f32(const float* image, const float* z, const float* flow, const float* maskz, const void* group_max,
+                      float* accum, int n, int h, int w, int group_size, void* stream);
+int g3_warp_resolve_f32(const float* accum, float* frame, float* mask, float* depth, int n, int h, int w, void* stream);
+int g3_mesh_occlusion_f32(const float* cam_points, const uint8_t* boundary_mask, const float* K, const float* Kinv,
+                          float* pts_ds, uint8_t* mask_ds, void* tmin, float* frame, float* mask, float* depth, int n, int h,
+                          int w, int factor, void* stream);
+/* cache construction: unproject_points(is_depth=True) (forward_warp_utils_pytorch.py:410-460; c2w = inverse(w2c), Kinv =
+ * inverse(K), both [n][..] f32 computed by the host) and reliable_depth_mask_range_batch (:338-353) -> u8 mask. */
+int g3_unproject_points_f32(const float* depth, const float* c2w, const float* Kinv, float* points, int n, int h, int w,
+                            void* stream);
+int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int n, int h, int w, int window, float ratio_thresh,
+                               float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
