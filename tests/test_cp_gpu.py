@@ -1,0 +1,19 @@
+"""GPU: context-parallel denoise step with the real HIP kernels == the non-CP step, 2 ranks sharing cuda:0 over gloo
+(tools/cp_check.py; RCCL itself needs one GPU per rank and is exercised by the driver's multi-GPU bench)."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_context_parallel_step_matches_single_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(ROOT / "tools" / "cp_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "[cp_check] OK" in r.stdout

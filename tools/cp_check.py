@@ -1,0 +1,64 @@
+"""Context-parallel end-to-end check with the REAL HIP kernels on ONE GPU: N ranks (torchrun) share cuda:0 and talk over
+gloo (RCCL refuses several ranks on one device); each rank compares the CP denoise step on its frame shard against
+the same step computed without CP on the full latent. Exercises dit.enable_context_parallel, table slicing,
+ContextParallelAttention (all-gather-KV in head groups) and the sampler's CP splits exactly as bench.py --gpus N does.
+
+  torchrun --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/cp_check.py
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from gen3c_amd.dit import VideoExtendGeneralDIT  # noqa: E402
+from gen3c_amd.parallel import init_distributed, parallel_state, split_inputs_cp  # noqa: E402
+from gen3c_amd.sampler import Gen3CDenoiser, VideoExtendCondition, add_condition_video_indicator_and_video_input_mask  # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    init_distributed("gloo")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parallel_state.initialize_model_parallel(context_parallel_size=world)
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(max_img_h=64, max_img_w=64, max_frames=32, in_channels=81, model_channels=512, num_blocks=2, num_heads=4,
+                                adaln_lora_dim=64, crossattn_emb_channels=256, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=11)
+    B, T, H, W, M = 1, 4 * world, 16, 24, 64
+    rs = np.random.RandomState(3)
+    nrm = lambda shape, std: torch.from_numpy((rs.standard_normal(shape) * std).astype(np.float32)).to(torch.bfloat16).to(dev)
+    den = Gen3CDenoiser(net, state_shape=(16, T, H, W))
+    den.scheduler.set_timesteps(35)
+    xt = nrm((B, 16, T, H, W), den.scheduler.init_noise_sigma)
+    gt, pose, ctx = nrm((B, 16, T, H, W), 0.5), nrm((B, 64, T, H, W), 0.5), nrm((B, M, 256), 0.2)
+    pad = torch.zeros(B, 1, 8 * H, 8 * W, device=dev, dtype=torch.bfloat16)
+
+    def cond(p):
+        c = VideoExtendCondition(crossattn_emb=ctx, padding_mask=pad, fps=torch.tensor([24.0], device=dev), video_cond_bool=True,
+                                 condition_video_pose=p)
+        return add_condition_video_indicator_and_video_input_mask(gt, c, 1)
+
+    c, u = cond(pose), cond(torch.zeros_like(pose))
+    full = den.denoise_step(xt, 5, c, u, 1.0, 0.001, 1)  # no CP: every rank computes the whole thing
+    net.enable_context_parallel(parallel_state.get_context_parallel_group())
+    part = den.denoise_step(split_inputs_cp(xt, 2, net.cp_group), 5, c, u, 1.0, 0.001, 1)
+    torch.cuda.synchronize()
+    ref = split_inputs_cp(full, 2, net.cp_group).float()
+    rel = float((part.float() - ref).norm() / ref.norm())
+    mx = float((part.float() - ref).abs().max())
+    print(f"[cp_check] rank {rank}/{world}: CP vs non-CP denoise step rel_l2={rel:.3e} max_abs={mx:.3e}", flush=True)
+    ok = torch.tensor([1.0 if (rel < 5e-3 and np.isfinite(rel)) else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    if ok.item() != 1.0:
+        sys.exit(1)
+    if rank == 0:
+        print("[cp_check] OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()
