@@ -26,6 +26,7 @@ int g3_check_launch(const char* what);
 
 // runtime switches for A/B measurements (g3_set_option); defaults come from the environment on first use
 extern int g3_opt_gemm_regstage;  // 1: register-staged GEMM even when the direct-to-LDS path applies
+extern int g3_opt_gemm_rowmajor_tiles;  // 1: plain row-major tile order inside an XCD run (A/B); 0: 4-token-tile super-rows
 extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }

@@ -30,6 +30,7 @@ constexpr int NTHREADS = 512;
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3 };
 
 struct GemmParams {
+    int tile_order_rowmajor;
     const bf16_t* A; int64_t lda;
     const bf16_t* W; int64_t ldw;
     bf16_t* C; int64_t ldc;
@@ -60,18 +61,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
-    // XCD-aware tile order: dispatch puts block b on XCD b%8. Give each XCD a contiguous run of tiles.
-    // tiles are enumerated feature-tile-fastest inside a token tile so neighbours share the A panel in L2.
+    // XCD-aware tile order: dispatch puts block b on XCD b%8; give each XCD a contiguous run of a global tile order
+    // (bijective for any tile count). The order itself is built for the private 4 MiB L2s: token tiles are taken in
+    // super-rows of GM=4 and swept feature-tile by feature-tile (token tile fastest), so the ~32 workgroups an XCD
+    // runs concurrently form an ~(4 token x 8 feature) block: 12 operand panels feed 32 tiles instead of 33.
     const int nblk = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, slot = bid >> 3;
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        bid = base + slot;  // bijective for any nblk
+        bid = base + slot;
     }
-    const int tile_m = bid / p.tiles_n;
-    const int tile_n = bid - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    if (p.tile_order_rowmajor) {
+        tile_m = bid / p.tiles_n;
+        tile_n = bid - tile_m * p.tiles_n;
+    } else {
+        constexpr int GM = 4;
+        const int per_group = GM * p.tiles_n;
+        const int grp = bid / per_group;
+        const int within = bid - grp * per_group;
+        const int gm = min(GM, p.tiles_m - grp * GM);  // last super-row may be shorter
+        tile_n = within / gm;
+        tile_m = grp * GM + (within - tile_n * gm);
+    }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -166,19 +180,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
 
         const bf16_t* cA = sA + buf * BM * BK;
         const bf16_t* cW = sW + buf * BN * BK;
+        // register double-buffered fragments: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks
+        bf16x8 wf[2][4], af[2][2];
+        auto load_frags = [&](int ks, int slot) {
+            const int chunk = 2 * ks + g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[slot][i] = load_bf16x8(cW + lds_off(n_w0 + 32 * i + l31, chunk));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[slot][j] = load_bf16x8(cA + lds_off(m_w0 + 32 * j + l31, chunk));
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int chunk = 2 * ks + g;
-            bf16x8 wf[4], af[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = load_bf16x8(cW + lds_off(n_w0 + 32 * i + l31, chunk));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) af[j] = load_bf16x8(cA + lds_off(m_w0 + 32 * j + l31, chunk));
+            if (ks + 1 < 4) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
         }
 
         if (!STAGE_GLDS && t + 1 < nk) stage_write(buf ^ 1);
@@ -267,6 +286,7 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
     p.gate = (const bf16_t*)gate; p.gate_rows = gate_rows > 0 ? gate_rows : 1; p.ldg = ldg;
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case EPI_NONE: return launch<EPI_NONE>(p, s);
