@@ -27,7 +27,20 @@ constexpr int BN = 256;  // features per block tile
 constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3, EPI_BIAS_RESIDUAL = 4 };
+
+// Implicit-GEMM convolution geometry (channels-last activations [T][H][W][C], one batch item):
+// output row m = (to, yo, xo); tap (dt, dy, dx) reads input position
+//   ti = max(to*st + ot + dt, 0)   (causal: the first frame is replicated in front - CausalConv3d._replication_pad)
+//   yi = yo*sh + oh + dy, xi = xo*sw + ow + dx   (outside [0,Hi) x [0,Wi) -> zero padding)
+// and multiplies with the tap's [N][K] weight slab.
+struct ConvGeom {
+    int To, Ho, Wo, Ti, Hi, Wi;
+    int kt, kh, kw, st, sh, sw, ot, oh, ow;
+    int ntaps;
+    int64_t w_tap_stride;  // elements between consecutive tap slabs of W
+};
+__device__ __attribute__((aligned(16))) unsigned g3_zero_page[64];  // 256 zero bytes: source of padded taps on the LDS-DMA path
 
 struct GemmParams {
     int tile_order_rowmajor;
@@ -38,6 +51,7 @@ struct GemmParams {
     const bf16_t* gate; int gate_rows; int64_t ldg;  // gate[(m % gate_rows)][n]  (EPI_GATED_RESIDUAL) / bias (EPI_BIAS)
     const bf16_t* R; int64_t ldr;                     // residual rows
     int tiles_m, tiles_n;
+    ConvGeom cv;
 };
 
 G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
@@ -49,7 +63,8 @@ G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] b
 //                     SOURCE address (same involution as the read side). Needs K % 64 == 0 (no zero-fill on this path;
 //                     M/N tails read a clamped valid row whose results are never stored).
 // STAGE_GLDS = false: global -> VGPR -> ds_write_b128 with zero-fill guards (any K % 8 == 0).
-template <int EPI, bool STAGE_GLDS>
+// CONV = true: A rows are gathered per tap according to p.cv (implicit GEMM); K is the per-tap channel count.
+template <int EPI, bool STAGE_GLDS, bool CONV>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);  // [2][BM][BK]
@@ -104,13 +119,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         w_ptr[i] = p.W + (int64_t)(w_ok[i] ? (n0 + row) : 0) * p.ldw + ld_chunk * 8;
     }
 
+    // conv: per-row base input coordinates (before adding the tap offset)
+    int cbt[4], cby[4], cbx[4];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ld_row + 64 * i;
+            const int mm = m < p.M ? m : 0;
+            const int to = mm / (p.cv.Ho * p.cv.Wo);
+            const int rem = mm - to * (p.cv.Ho * p.cv.Wo);
+            const int yo = rem / p.cv.Wo;
+            const int xo = rem - yo * p.cv.Wo;
+            cbt[i] = to * p.cv.st + p.cv.ot;
+            cby[i] = yo * p.cv.sh + p.cv.oh;
+            cbx[i] = xo * p.cv.sw + p.cv.ow;
+        }
+    }
+    // source row of slot i for tap `tap`, or -1 for a zero (padded / out-of-range) row
+    auto conv_src_row = [&](int i, int tap) -> int64_t {
+        const int khw = p.cv.kh * p.cv.kw;
+        const int dt = tap / khw;
+        const int r2 = tap - dt * khw;
+        const int dy = r2 / p.cv.kw;
+        const int dx = r2 - dy * p.cv.kw;
+        int ti = cbt[i] + dt;
+        ti = ti < 0 ? 0 : ti;
+        const int yi = cby[i] + dy, xi = cbx[i] + dx;
+        const bool ok = a_ok[i] && ti < p.cv.Ti && yi >= 0 && yi < p.cv.Hi && xi >= 0 && xi < p.cv.Wi;
+        return ok ? ((int64_t)ti * p.cv.Hi + yi) * p.cv.Wi + xi : (int64_t)-1;
+    };
+    const int nkc = (p.K + BK - 1) / BK;  // K tiles per tap
+
     bf16x8 ra[4], rw[4];
-    auto stage_load = [&](int k0) {
+    auto stage_load = [&](int it) {
+        const int tap = CONV ? it / nkc : 0;
+        const int k0 = (CONV ? it - tap * nkc : it) * BK;
         const bool k_ok = (k0 + ld_chunk * 8) < p.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = (a_ok[i] && k_ok) ? load_bf16x8(a_ptr[i] + k0) : zero_bf16x8();
-            rw[i] = (w_ok[i] && k_ok) ? load_bf16x8(w_ptr[i] + k0) : zero_bf16x8();
+            if (CONV) {
+                const int64_t src = conv_src_row(i, tap);
+                ra[i] = (src >= 0 && k_ok) ? load_bf16x8(p.A + src * p.lda + ld_chunk * 8 + k0) : zero_bf16x8();
+                rw[i] = (w_ok[i] && k_ok) ? load_bf16x8(w_ptr[i] + tap * p.cv.w_tap_stride + k0) : zero_bf16x8();
+            } else {
+                ra[i] = (a_ok[i] && k_ok) ? load_bf16x8(a_ptr[i] + k0) : zero_bf16x8();
+                rw[i] = (w_ok[i] && k_ok) ? load_bf16x8(w_ptr[i] + k0) : zero_bf16x8();
+            }
         }
     };
     auto stage_write = [&](int buf) {
@@ -136,14 +190,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         ga[i] = p.A + (int64_t)ra_row * p.lda + src_chunk * 8;
         gw[i] = p.W + (int64_t)rw_row * p.ldw + src_chunk * 8;
     }
-    auto stage_glds = [&](int k0, int buf) {
+    auto stage_glds = [&](int it, int buf) {
+        const int tap = CONV ? it / nkc : 0;
+        const int k0 = (CONV ? it - tap * nkc : it) * BK;
         bf16_t* dA = sA + buf * BM * BK + wave * 64 * 8;  // wave-uniform base; the hardware adds lane*16 bytes
         bf16_t* dW = sW + buf * BN * BK + wave * 64 * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+            const bf16_t* asrc;
+            const bf16_t* wsrc;
+            if (CONV) {
+                const int64_t src = conv_src_row(i, tap);
+                asrc = src >= 0 ? p.A + src * p.lda + src_chunk * 8 + k0 : reinterpret_cast<const bf16_t*>(g3_zero_page) + src_chunk * 8;
+                wsrc = gw[i] + tap * p.cv.w_tap_stride + k0;
+            } else {
+                asrc = ga[i] + k0;
+                wsrc = gw[i] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
                                              (__attribute__((address_space(3))) void*)(dA + i * 512 * 8), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
                                              (__attribute__((address_space(3))) void*)(dW + i * 512 * 8), 16, 0, 0);
         }
     };
@@ -162,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = CONV ? nkc * p.cv.ntaps : nkc;
     if (STAGE_GLDS) {
         stage_glds(0, 0);
     } else {
@@ -174,8 +240,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
         if (t + 1 < nk) {
-            if (STAGE_GLDS) stage_glds((t + 1) * BK, buf ^ 1);  // buf^1 was last read in iteration t-1 (barrier passed)
-            else stage_load((t + 1) * BK);
+            if (STAGE_GLDS) stage_glds(t + 1, buf ^ 1);  // buf^1 was last read in iteration t-1 (barrier passed)
+            else stage_load(t + 1);
         }
 
         const bf16_t* cA = sA + buf * BM * BK;
@@ -210,8 +276,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         const int m = m0 + m_w0 + 32 * j + l31;
         if (m >= p.M) continue;
         bf16_t* crow = p.C + (int64_t)m * p.ldc;
-        const bf16_t* rrow = (EPI == EPI_GATED_RESIDUAL) ? (p.R + (int64_t)m * p.ldr) : nullptr;
-        const bf16_t* grow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS)
+        const bf16_t* rrow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS_RESIDUAL) ? (p.R + (int64_t)m * p.ldr) : nullptr;
+        const bf16_t* grow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL)
                                  ? (p.gate + (int64_t)(m % p.gate_rows) * p.ldg)
                                  : nullptr;
 #pragma unroll
@@ -237,6 +303,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
                     const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)gv[e];
+                } else if (EPI == EPI_BIAS_RESIDUAL) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + (float)gv[e]) + (float)rv[e];
                 }
                 bf16x4 o;
 #pragma unroll
@@ -247,25 +318,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
     }
 }
 
-template <int EPI, bool STAGE_GLDS>
-int launch_variant(const GemmParams& p, hipStream_t stream) {
+template <int EPI, bool STAGE_GLDS, bool CONV>
+int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);  // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI, STAGE_GLDS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int nblk = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, STAGE_GLDS>), dim3(nblk), dim3(NTHREADS), smem, stream, p);
-    return g3_check_launch("g3_gemm_bf16_nt");
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV>), dim3(nblk), dim3(NTHREADS), smem, stream, p);
+    return g3_check_launch(what);
 }
 
-template <int EPI>
-int launch(const GemmParams& p, hipStream_t stream) {
-    if ((p.K % BK) == 0 && !g3_opt_gemm_regstage) return launch_variant<EPI, true>(p, stream);
-    return launch_variant<EPI, false>(p, stream);
+template <int EPI, bool CONV>
+int launch(const GemmParams& p, hipStream_t stream, const char* what) {
+    if ((p.K % BK) == 0 && !g3_opt_gemm_regstage) return launch_variant<EPI, true, CONV>(p, stream, what);
+    return launch_variant<EPI, false, CONV>(p, stream, what);
 }
 
 }  // namespace
@@ -287,17 +358,53 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
+    p.cv = ConvGeom{};
     hipStream_t s = (hipStream_t)stream;
+    const char* what = "g3_gemm_bf16_nt";
     switch (epilogue) {
-        case EPI_NONE: return launch<EPI_NONE>(p, s);
-        case EPI_GELU: return launch<EPI_GELU>(p, s);
+        case EPI_NONE: return launch<EPI_NONE, false>(p, s, what);
+        case EPI_GELU: return launch<EPI_GELU, false>(p, s, what);
         case EPI_GATED_RESIDUAL:
             if (!gate || !residual || (ldg & 3) || (ldr & 3) || (((uintptr_t)gate | (uintptr_t)residual) & 7))
                 return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: gated-residual epilogue needs 8-byte aligned gate+residual");
-            return launch<EPI_GATED_RESIDUAL>(p, s);
+            return launch<EPI_GATED_RESIDUAL, false>(p, s, what);
         case EPI_BIAS:
             if (!gate || (ldg & 3) || ((uintptr_t)gate & 7)) return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: bias epilogue needs bias");
-            return launch<EPI_BIAS>(p, s);
+            return launch<EPI_BIAS, false>(p, s, what);
+        case EPI_BIAS_RESIDUAL:
+            if (!gate || !residual || (ldg & 3) || (ldr & 3) || (((uintptr_t)gate | (uintptr_t)residual) & 7))
+                return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: bias-residual epilogue needs 8-byte aligned bias+residual");
+            return launch<EPI_BIAS_RESIDUAL, false>(p, s, what);
         default: return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: unknown epilogue %d", epilogue);
     }
+}
+
+// Causal 3-D convolution as an implicit GEMM over channels-last activations.
+//   in  [Ti*Hi*Wi][ld_in]  (C_in = K valid channels per position), w [kt*kh*kw][N][ldw] (tap-major, K contiguous),
+//   out [To*Ho*Wo][ld_out]; bias [N] (may be NULL), residual [To*Ho*Wo][ldr] (may be NULL) added after the bias.
+extern "C" int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                                 int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho,
+                                 int Wo, int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* stream) {
+    if (!in || !w || !out) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: null operand");
+    if (K <= 0 || N <= 0 || (K & 7) || (ld_in & 7) || (ldw & 7) || (N & 3) || (ld_out & 3))
+        return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: need K, ld_in, ldw %% 8 == 0 and N, ld_out %% 4 == 0 (K=%d N=%d)", K, N);
+    if (Ti <= 0 || Hi <= 0 || Wi <= 0 || To <= 0 || Ho <= 0 || Wo <= 0 || kt <= 0 || kh <= 0 || kw <= 0 || st <= 0 || sh <= 0 || sw <= 0)
+        return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: bad geometry");
+    if ((int64_t)To * Ho * Wo > 0x7fffffffLL) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: too many output positions");
+    if ((((uintptr_t)in | (uintptr_t)w) & 15) || ((uintptr_t)out & 7)) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: misaligned pointer");
+    if (residual && ((ldr & 3) || ((uintptr_t)residual & 7))) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: misaligned residual");
+    if (residual && !bias) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: residual without bias is not instantiated");
+    GemmParams p;
+    p.A = (const bf16_t*)in; p.lda = ld_in; p.W = (const bf16_t*)w; p.ldw = ldw; p.C = (bf16_t*)out; p.ldc = ld_out;
+    p.M = To * Ho * Wo; p.N = N; p.K = K;
+    p.gate = (const bf16_t*)bias; p.gate_rows = 1; p.ldg = 0;
+    p.R = (const bf16_t*)residual; p.ldr = ldr;
+    p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
+    p.cv = ConvGeom{To, Ho, Wo, Ti, Hi, Wi, kt, kh, kw, st, sh, sw, ot, oh, ow, kt * kh * kw, (int64_t)N * ldw};
+    hipStream_t s = (hipStream_t)stream;
+    const char* what = "g3_conv3d_cl_bf16";
+    if (residual) return launch<EPI_BIAS_RESIDUAL, true>(p, s, what);
+    if (bias) return launch<EPI_BIAS, true>(p, s, what);
+    return launch<EPI_NONE, true>(p, s, what);
 }

@@ -31,6 +31,7 @@ extern "C" {
 #define G3_EPI_GELU 1           /* C = gelu_erf(A.W^T)      attention.py:86,94-99 (GPT2FeedForward)            */
 #define G3_EPI_GATED_RESIDUAL 2 /* C = R + gate[m%rows] * (A.W^T)   blocks.py:455-471 (x + gate * block(...))   */
 #define G3_EPI_BIAS 3           /* C = A.W^T + bias[m%rows]                                                     */
+#define G3_EPI_BIAS_RESIDUAL 4  /* C = A.W^T + bias[m%rows] + R                                                 */
 
 const char* g3_last_error(void);
 int g3_abi_version(void);
@@ -129,6 +130,30 @@ int g3_unproject_points_f32(const float* depth, const float* c2w, const float* K
                             void* stream);
 int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int n, int h, int w, int window, float ratio_thresh,
                                float eps, void* stream);
+
+/* ---- causal video tokenizer (Cosmos-Tokenize1-CV8x8x8; tokenizer/modules/{layers3d,patching,utils}.py) ---------------
+ * Activations are channels-last bf16 [T][H][W][C] for one batch item.
+ * conv3d_cl: CausalConv3d (layers3d.py:50-97) as an implicit GEMM on the MFMA kernel. Output position (to,yo,xo), tap
+ *   (dt,dy,dx) reads ti = max(to*st+ot+dt, 0) (first frame replicated in front), yi = yo*sh+oh+dy, xi = xo*sw+ow+dx
+ *   (outside the frame = zero padding). w is tap-major [kt*kh*kw][N][ldw]; bias [N] or NULL; residual (needs bias) is
+ *   added after the bias: out = conv(in) + bias + residual  (res-block skip, hybrid up/down-sample "+ x").
+ * groupnorm_swish_cl: CausalNormalize = GroupNorm(1 group, eps) per frame (+ optional x*sigmoid(x)); stats_f64 is a
+ *   [frames][2] double scratch. haar3d_(un)patch: Patcher3D/UnPatcher3D, patch_size 4; video is planar [3][T][H][W].
+ * resample_cl modes: 0 avg-pool(1,2,2) on right/bottom zero pad, 1 avg-pool(2,1,1) on front-replicated input,
+ *   2 repeat_interleave(2) in time minus the first frame, 3 repeat_interleave(2) in H and W (layers3d.py:135-234).
+ * softmax_rows / transpose2d / temporal_attn_cl: CausalAttnBlock and CausalTemporalAttnBlock (layers3d.py:345-427). */
+int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                      int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
+                      int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* stream);
+int g3_groupnorm_swish_cl_bf16(const void* x, int64_t ld, const void* gamma, const void* beta, void* stats_f64, void* out,
+                               int64_t ldo, int frames, int rows_per_frame, int C, float eps, int swish, void* stream);
+int g3_haar3d_patch_bf16(const void* video, void* out, int T, int H, int W, void* stream);
+int g3_haar3d_unpatch_bf16(const void* coef, int64_t ld, void* video, int Tp, int Hp, int Wp, void* stream);
+int g3_resample_cl_bf16(const void* in, void* out, int Ti, int Hi, int Wi, int C, int mode, void* stream);
+int g3_softmax_rows_bf16(void* x, int64_t ld, int rows, int n, float scale, void* stream);
+int g3_transpose2d_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, void* stream);
+int g3_temporal_attn_cl_bf16(const void* q, const void* k, const void* v, void* o, int T, int HW, int C, float scale,
+                             void* stream);
 
 #ifdef __cplusplus
 }

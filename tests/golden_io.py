@@ -25,3 +25,9 @@ def load_dit_case(name: str):
         padding_mask=torch.from_numpy(z["padding_mask"]),
     )
     return cfg, sd, inputs, torch.from_numpy(z["y_ref"])
+
+
+def load_tokenizer_case(name: str = "tokenizer_small"):
+    z = np.load(GOLD / f"{name}.npz")
+    sd = {k[2:]: from_bf16_bits(z[k]) for k in z.files if k.startswith("w:")}
+    return sd, from_bf16_bits(z["x"]), torch.from_numpy(z["z_ref"]), from_bf16_bits(z["zin"]), torch.from_numpy(z["y_ref"])
