@@ -174,8 +174,16 @@ def main():
         avg_ms = sum(ms for _, ms in self_attn) / len(self_attn)
         flops_launch = sum(4.0 * m["Sq"] * m["Skv"] * m["H"] * 128 * m["B"] for m, _ in self_attn) / len(self_attn)
         ach = flops_launch / (avg_ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="flash_attn_fwd_kernel<0>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape), if present
+        try:
+            tj = json.loads((ROOT / "profiles" / "r1_attn_traffic.json").read_text())
+            m0 = self_attn[0][0]
+            if world == 1 and tj["shape"] == {"Sq": m0["Sq"], "Skv": m0["Skv"], "H": m0["H"], "B": m0["B"]}:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        roof = dict(bound="mfma", kernel="flash_attn_fwd_v2_kernel<0>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
                     flops_per_launch=flops_launch)
 
     if rank == 0:
