@@ -28,7 +28,7 @@ static int env_int(const char* name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 int g3_opt_gemm_regstage = env_int("G3_GEMM_REGSTAGE", 0);
-int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 2);
+int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 3);
 int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 
 extern "C" int g3_set_option(const char* name, int value) {

@@ -24,6 +24,7 @@
 //     K/V^T panels.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -306,6 +307,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
     };
 
     const int krow_perm = swap23(l31);
+    // per-lane LDS element offsets, computed once: the XOR swizzle depends on the lane's row only, so the 32-row block
+    // (mb / d) and the ring slot become compile-time immediates of the ds_read
+    int koff[8], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(krow_perm, 2 * ks + g);   // (32*mb + row) & 15 == row & 15
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) voff[s4] = v_off(l31, 2 * s4 + g);          // ((32*d + row) >> 1) & 7 == (row >> 1) & 7
     auto qk = [&](f32x16 (&S)[2], int kbuf) {
         const bf16_t* cK = sK + kbuf * KVB * HD;
 #pragma unroll
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
             for (int r = 0; r < 16; ++r) S[mb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = load_bf16x8(cK + k_off(32 * mb + krow_perm, 2 * ks + g));
+                const bf16x8 kf = load_bf16x8(cK + 32 * mb * HD + koff[ks]);
                 S[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[mb], 0, 0, 0);
             }
         }
@@ -344,9 +352,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
     qk(SA, 0);
 
     // one tile: softmax(S_cur) + PV(t), overlapped with S_next = QK^T(t+1)
-    auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, bool has_next) {
+    // has_next and par (= t & 1, the LDS ring slot of V(t); K(t+1) sits in slot par^1) are compile-time at every call
+    // site, so ring-slot offsets fold into ds_read immediates and the ragged-tile masking exists only in the final tile.
+    auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, auto has_next_c, auto par_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        constexpr int par = decltype(par_c)::value;
         const int kv0 = t * KVB;
-        if (kv0 + KVB > p.Skv) {  // ragged last tile
+        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
             if (t + 2 < nt) load_k(kv0 + 2 * KVB);
             load_v(kv0 + KVB);
             __builtin_amdgcn_s_setprio(1);
-            qk(S_next, (t + 1) & 1);
+            qk(S_next, par ^ 1);
             __builtin_amdgcn_s_setprio(0);
         }
         const float neg_m = -m_run;
@@ -395,34 +407,298 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
                 pb[2 * mb + (r >> 3)][r & 7] = f32_to_bf16(pv);
             }
         l_run += psum;
-        const bf16_t* cV = sV + (t & 1) * HD * KVB;
+        const bf16_t* cV = sV + par * HD * KVB;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const bf16x8 vf = load_bf16x8(cV + v_off(32 * d + l31, 2 * s + g));
+                const bf16x8 vf = load_bf16x8(cV + 32 * d * KVB + voff[s]);
                 accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s], accO[d], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
         if (has_next) {
-            if (t + 2 < nt) write_k(t & 1);   // K(t+2) replaces K(t)   (last read in iteration t-1)
-            write_v((t + 1) & 1);             // V(t+1) replaces V(t-1) (last read in iteration t-1)
+            if (t + 2 < nt) write_k(par);     // K(t+2) replaces K(t)   (last read in iteration t-1)
+            write_v(par ^ 1);                 // V(t+1) replaces V(t-1) (last read in iteration t-1)
             __syncthreads();
         }
     };
 
-    int t = 0;
+    using True = std::integral_constant<bool, true>;
+    using False = std::integral_constant<bool, false>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;  // always even here
     for (; t + 2 < nt; t += 2) {
-        tile(SA, SB, t, true);
-        tile(SB, SA, t + 1, true);
+        tile(SA, SB, t, True{}, P0{});
+        tile(SB, SA, t + 1, True{}, P1{});
     }
     if (t + 1 < nt) {  // two tiles left
-        tile(SA, SB, t, true);
-        tile(SB, SA, t + 1, false);
+        tile(SA, SB, t, True{}, P0{});
+        tile(SB, SA, t + 1, False{}, P1{});
     } else {           // one tile left
-        tile(SA, SB, t, false);
+        tile(SA, SB, t, False{}, P0{});
+    }
+
+    const float l_tot = xor32_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(accO[d][4 * q4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * d + 8 * q4 + 4 * g) = o;
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3: v2's algorithm with an explicitly pipelined instruction stream.
+//   * K / V^T tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (LDS-DMA): no staging VGPRs, no ds_write pass; the XOR
+//     swizzle is applied to the per-lane SOURCE chunk (the LDS image a wave writes is lane-linear);
+//   * every MFMA's LDS operand is read 3 MFMAs ahead through a 4-deep fragment ring in registers;
+//   * the softmax VALU of tile t is sliced behind the 16 QK^T MFMAs of tile t+1 and the first 8 P.V MFMAs of tile t
+//     (each P slice is ready just before the P.V step that consumes it); the row-max chain of tile t+1 rides behind the
+//     last 8 P.V MFMAs; __builtin_amdgcn_sched_group_barrier pins that interleave in the emitted stream;
+//   * no per-cluster s_setprio (it fences the scheduler); the second-dispatched half of the workgroup gets static prio 1.
+// Needs vt_row >= ceil64(S_kv) (true for g3_transpose_v_bf16's output): the V^T tail is read, not guarded.
+// ---------------------------------------------------------------------------------------------------------------
+#define G3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSR = 0x100, SGB_TRANS = 0x400;
+
+template <int CTX>
+__global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
+    bf16_t* sV = sK + 2 * KVB * HD;                     // [2][128][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+    const int head = blockIdx.y;
+    const int batch = blockIdx.z;
+
+    const bf16_t* Qb = p.Q + batch * p.q_batch + head * p.q_head;
+    const bf16_t* Kb = p.K + batch * p.k_batch + head * p.k_head;
+    const bf16_t* Vb = p.Vt + batch * p.vt_batch + head * p.vt_head;
+    bf16_t* Ob = p.O + batch * p.o_batch + head * p.o_head;
+
+    const int q_idx = blockIdx.x * BQ + wave * QB + l31;
+    const bool q_ok = q_idx < p.Sq;
+    bf16x8 qf[8];
+    {
+        const bf16_t* qrow = Qb + (int64_t)(q_ok ? q_idx : 0) * p.q_row + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = q_ok ? load_bf16x8(qrow + 16 * ks) : zero_bf16x8();
+    }
+
+    // ---- LDS-DMA staging. K tile: 1024 16-B slots (row = slot>>4, chunk = slot&15); V^T tile: 1024 slots (row = slot>>3,
+    // chunk = slot&7). Thread tid fills slots tid and tid+512 of each; the lane fetches the LOGICAL chunk that the
+    // swizzled read side expects to find in its physical slot.
+    // All per-lane source addresses are 32-bit BYTE offsets from the (wave-uniform) head base pointers: one v_add per DMA.
+    const int k_row0 = tid >> 4, k_src_chunk = (tid & 15) ^ (k_row0 & 15);          // rows k_row0 and k_row0+32 share row&15
+    const int v_row0 = tid >> 3, v_src_chunk = (tid & 7) ^ ((v_row0 >> 1) & 7);     // rows v_row0 and v_row0+64 share (row>>1)&7
+    const char* Kbytes = reinterpret_cast<const char*>(Kb);
+    const char* Vbytes = reinterpret_cast<const char*>(Vb);
+    const uint32_t k_row_bytes = (uint32_t)p.k_row * 2u;
+    const uint32_t k_lane = (uint32_t)k_row0 * k_row_bytes + (uint32_t)k_src_chunk * 16u;   // + kv0 * k_row_bytes (+ 32 rows)
+    const uint32_t v_lane0 = (uint32_t)v_row0 * (uint32_t)p.vt_row * 2u + (uint32_t)v_src_chunk * 16u;  // + kv0 * 2
+    const uint32_t v_lane1 = v_lane0 + 64u * (uint32_t)p.vt_row * 2u;
+    const uint32_t k_last = (uint32_t)(p.Skv - 1) * k_row_bytes + (uint32_t)k_src_chunk * 16u;  // clamp target for ragged tails
+    auto dma_k = [&](int kv0, int slot) {
+        bf16_t* d = sK + slot * KVB * HD + wave * 64 * 8;
+        uint32_t o0 = k_lane + (uint32_t)kv0 * k_row_bytes;
+        uint32_t o1 = o0 + 32u * k_row_bytes;
+        o0 = min(o0, k_last | 0u);  // rows past S_kv-1 re-read the last row (their scores are masked); chunk bits agree
+        o1 = min(o1, k_last | 0u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kbytes + o0),
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kbytes + o1),
+                                         (__attribute__((address_space(3))) void*)(d + 512 * 8), 16, 0, 0);
+    };
+    auto dma_v = [&](int kv0, int slot) {
+        bf16_t* d = sV + slot * HD * KVB + wave * 64 * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane0 + (uint32_t)kv0 * 2u),
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane1 + (uint32_t)kv0 * 2u),
+                                         (__attribute__((address_space(3))) void*)(d + 512 * 8), 16, 0, 0);
+    };
+
+    const int krow_perm = swap23(l31);
+    int koff[8], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(krow_perm, 2 * ks + g);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) voff[s4] = v_off(l31, 2 * s4 + g);
+
+    f32x16 accO[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accO[d][r] = 0.f;
+    float m_run = -1e30f;
+    float l_run = 0.f;
+    const float c = p.scale_log2;
+    const int nt = (p.Skv + KVB - 1) / KVB;
+
+    auto row_max = [&](const f32x16 (&S)[2]) -> float {  // two independent v_max3 chains (one per 32-kv block)
+        float ma = max3(S[0][0], S[0][1], S[0][2]);
+        float mb2 = max3(S[1][0], S[1][1], S[1][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) {
+            ma = max3(ma, S[0][r], S[0][r + 1]);
+            mb2 = max3(mb2, S[1][r], S[1][r + 1]);
+        }
+        return xor32_max(max3(ma, mb2, max3(S[0][15], S[1][15], S[1][15]))) * c;
+    };
+    auto mask_tail = [&](f32x16 (&S)[2], int kv0) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + 32 * mb + 16 * (r >> 3) + 8 * g + (r & 7);
+                if (kv >= p.Skv) S[mb][r] = -INFINITY;
+            }
+    };
+
+    // ---- prologue
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (nt > 1) dma_k(KVB, 1);
+    __syncthreads();
+    f32x16 SA[2], SB[2];
+    {
+        const bf16_t* cK = sK;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) SA[mb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                SA[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_bf16x8(cK + 32 * mb * HD + koff[ks]), qf[ks], SA[mb], 0, 0, 0);
+        }
+    }
+    if (nt == 1 && KVB > p.Skv) mask_tail(SA, 0);
+    float mx_cur = row_max(SA);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+
+    auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, auto has_next_c, auto par_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        constexpr int par = decltype(par_c)::value;
+        const int kv0 = t * KVB;
+        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: redo its row max on masked scores
+            mask_tail(S_cur, kv0);
+            mx_cur = row_max(S_cur);
+        }
+        if (has_next) {
+            if (t + 2 < nt) dma_k(kv0 + 2 * KVB, par);  // K(t+2) -> slot of K(t)   (last read before the previous barrier)
+            dma_v(kv0 + KVB, par ^ 1);                  // V(t+1) -> slot of V(t-1)
+        }
+        if (__any(mx_cur - m_run > RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx_cur);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+        }
+        const float neg_m = -m_run;
+        float psum[4] = {0.f, 0.f, 0.f, 0.f};  // one short add chain per slice (no 32-deep dependency)
+        bf16x8 pb[4];
+        auto softmax_slice = [&](int sl) {  // 8 scores -> P fragment of P.V step sl
+            const int mb = sl >> 1, r0 = (sl & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S_cur[mb][r0 + j], c, neg_m));
+                psum[sl] += pv;
+                pb[sl][j] = f32_to_bf16(pv);
+            }
+        };
+
+        // ---- region A: S_next = K(t+1).Q^T (16 MFMA, fragments 3 ahead)  ||  softmax slices 0 and 1
+        if (has_next) {
+            const bf16_t* cK = sK + (par ^ 1) * KVB * HD;
+            bf16x8 kf[4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) kf[i] = load_bf16x8(cK + 32 * (i >> 3) * HD + koff[i & 7]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S_next[mb][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i + 3 < 16) kf[(i + 3) & 3] = load_bf16x8(cK + 32 * ((i + 3) >> 3) * HD + koff[(i + 3) & 7]);
+                S_next[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], S_next[i >> 3], 0, 0, 0);
+                if (i == 3) softmax_slice(0);
+                if (i == 11) softmax_slice(1);
+            }
+            G3_SGB(SGB_DSR, 3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                G3_SGB(SGB_MFMA, 1);
+                if (i + 3 < 16) G3_SGB(SGB_DSR, 1);
+                G3_SGB(SGB_VALU, 5);
+                G3_SGB(SGB_TRANS, 1);
+            }
+        } else {
+            softmax_slice(0);
+            softmax_slice(1);
+        }
+
+        // ---- region B: O^T += V^T(t).P^T (16 MFMA, fragments 3 ahead) || softmax slices 2,3 || row max of tile t+1
+        {
+            const bf16_t* cV = sV + par * HD * KVB;
+            bf16x8 vf[4];
+            // MFMA order i: step s = i>>2, output block d = i&3
+#pragma unroll
+            for (int i = 0; i < 3; ++i) vf[i] = load_bf16x8(cV + 32 * (i & 3) * KVB + voff[i >> 2]);
+            softmax_slice(2);
+            float mx_next = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i + 3 < 16) vf[(i + 3) & 3] = load_bf16x8(cV + 32 * ((i + 3) & 3) * KVB + voff[(i + 3) >> 2]);
+                accO[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i & 3], pb[i >> 2], accO[i & 3], 0, 0, 0);
+                if (i == 3) softmax_slice(3);
+                if (has_next && i == 7) mx_next = row_max(S_next);
+            }
+            G3_SGB(SGB_DSR, 3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                G3_SGB(SGB_MFMA, 1);
+                if (i + 3 < 16) G3_SGB(SGB_DSR, 1);
+                G3_SGB(SGB_VALU, 6);
+                G3_SGB(SGB_TRANS, 1);
+            }
+            l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
+            mx_cur = mx_next;
+        }
+        if (has_next) __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
+    };
+
+    using True = std::integral_constant<bool, true>;
+    using False = std::integral_constant<bool, false>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        tile(SA, SB, t, True{}, P0{});
+        tile(SB, SA, t + 1, True{}, P1{});
+    }
+    if (t + 1 < nt) {
+        tile(SA, SB, t, True{}, P0{});
+        tile(SB, SA, t + 1, False{}, P1{});
+    } else {
+        tile(SA, SB, t, False{}, P0{});
     }
 
     const float l_tot = xor32_sum(l_run);
@@ -466,11 +742,13 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
-    const int variant = g3_opt_attn_variant;  // 1 = non-pipelined v1 kernel (kept for A/B measurements), else v2
+    int variant = g3_opt_attn_variant;  // 1 = non-pipelined, 2 = software-pipelined, 3 = LDS-DMA + pinned interleave (default)
+    if (variant == 3 && vt_row < ((Skv + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
     if (!attr_set) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>)};
-        for (int i = 0; i < 4; ++i) {
+        const void* fns[6] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1>)};
+        for (int i = 0; i < 6; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -481,9 +759,12 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     if (variant == 1) {
         if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(flash_attn_fwd_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-    } else {
+    } else if (variant == 2) {
         if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+    } else {
+        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_v3_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(flash_attn_fwd_v3_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
     }
     return g3_check_launch("g3_flash_attn_fwd_bf16");
 }
