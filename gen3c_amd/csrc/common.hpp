@@ -27,6 +27,7 @@ int g3_check_launch(const char* what);
 // runtime switches for A/B measurements (g3_set_option); defaults come from the environment on first use
 extern int g3_opt_gemm_regstage;  // 1: register-staged GEMM even when the direct-to-LDS path applies
 extern int g3_opt_gemm_rowmajor_tiles;  // 1: plain row-major tile order inside an XCD run (A/B); 0: 4-token-tile super-rows
+extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop (no sched_group_barrier pinning) (A/B)
 extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }
@@ -42,4 +43,16 @@ G3_DEVICE bf16x8 zero_bf16x8() {
 G3_DEVICE float wave_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
 G3_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below one bf16 ulp of the GELU output): 1 rcp + 1 exp + 6 fma
+// instead of libm's ~40-instruction erff in a GEMM epilogue that evaluates it 128 times per lane.
+G3_DEVICE float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 G3_DEVICE float silu(float x) { return x / (1.0f + __expf(-x)); }

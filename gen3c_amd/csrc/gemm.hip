@@ -64,7 +64,7 @@ G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] b
 //                     M/N tails read a clamped valid row whose results are never stored).
 // STAGE_GLDS = false: global -> VGPR -> ds_write_b128 with zero-fill guards (any K % 8 == 0).
 // CONV = true: A rows are gathered per tap according to p.cv (implicit GEMM); K is the per-tap channel count.
-template <int EPI, bool STAGE_GLDS, bool CONV>
+template <int EPI, bool STAGE_GLDS, bool CONV, bool PIN>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);  // [2][BM][BK]
@@ -265,6 +265,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
         }
+        // pin the stream: the 6 fragment reads of k-step ks+1 ride behind the first 6 of the 8 MFMAs of k-step ks, so
+        // only the first k-step after the barrier waits on LDS latency (0x8 = MFMA, 0x100 = DS read)
+        if (PIN) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    if (ks + 1 < 4 && m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
 
         if (!STAGE_GLDS && t + 1 < nk) stage_write(buf ^ 1);
         __syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) here: tile t+1 has landed for every wave
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
                 if (EPI == EPI_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
                 } else if (EPI == EPI_GATED_RESIDUAL) {
                     const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
                     const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
@@ -318,25 +331,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
     }
 }
 
-template <int EPI, bool STAGE_GLDS, bool CONV>
+template <int EPI, bool STAGE_GLDS, bool CONV, bool PIN>
 int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);  // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV, PIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int nblk = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV>), dim3(nblk), dim3(NTHREADS), smem, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, STAGE_GLDS, CONV, PIN>), dim3(nblk), dim3(NTHREADS), smem, stream, p);
     return g3_check_launch(what);
 }
 
 template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
-    if ((p.K % BK) == 0 && !g3_opt_gemm_regstage) return launch_variant<EPI, true, CONV>(p, stream, what);
-    return launch_variant<EPI, false, CONV>(p, stream, what);
+    const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
+    if (g3_opt_gemm_unpinned) return glds ? launch_variant<EPI, true, CONV, false>(p, stream, what) : launch_variant<EPI, false, CONV, false>(p, stream, what);
+    return glds ? launch_variant<EPI, true, CONV, true>(p, stream, what) : launch_variant<EPI, false, CONV, true>(p, stream, what);
 }
 
 }  // namespace

@@ -35,7 +35,8 @@ extern "C" {
 
 const char* g3_last_error(void);
 int g3_abi_version(void);
-/* runtime switches for A/B measurements: "gemm_regstage" (0/1), "attn_variant" (1 = non-pipelined, 2 = pipelined). */
+/* runtime switches for A/B measurements: "gemm_regstage", "gemm_rowmajor_tiles", "gemm_unpinned" (0/1),
+ * "attn_variant" (1 = non-pipelined, 2 = software-pipelined, 3 = LDS-DMA + pinned interleave, the default). */
 int g3_set_option(const char* name /*host*/, int value);
 int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name /*host*/, int arch_name_len);
 
