@@ -472,7 +472,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
 #define G3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSR = 0x100, SGB_TRANS = 0x400;
 
-template <int CTX>
+// QA / QBV: VALU slots pinned behind each MFMA of region A / region B (sched_group_barrier quotas).
+template <int CTX, int QA, int QBV>
 __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             for (int i = 0; i < 16; ++i) {
                 G3_SGB(SGB_MFMA, 1);
                 if (i + 3 < 16) G3_SGB(SGB_DSR, 1);
-                G3_SGB(SGB_VALU, 5);
+                G3_SGB(SGB_VALU, QA);
                 G3_SGB(SGB_TRANS, 1);
             }
         } else {
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             for (int i = 0; i < 16; ++i) {
                 G3_SGB(SGB_MFMA, 1);
                 if (i + 3 < 16) G3_SGB(SGB_DSR, 1);
-                G3_SGB(SGB_VALU, 6);
+                G3_SGB(SGB_VALU, QBV);
                 G3_SGB(SGB_TRANS, 1);
             }
             l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
@@ -717,6 +718,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     }
 }
 
+
+
 }  // namespace
 
 extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k,
@@ -742,12 +745,12 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
-    int variant = g3_opt_attn_variant;  // 1 = non-pipelined, 2 = software-pipelined, 3 = LDS-DMA + pinned interleave (default)
-    if (variant == 3 && vt_row < ((Skv + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
+    int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined (both kept for A/B), 3 LDS-DMA + pinned interleave (default)
+    if (variant >= 3 && vt_row < ((Skv + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
     if (!attr_set) {
         const void* fns[6] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1>)};
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8>)};
         for (int i = 0; i < 6; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -756,15 +759,12 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     }
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;
-    if (variant == 1) {
-        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(flash_attn_fwd_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-    } else if (variant == 2) {
-        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(flash_attn_fwd_v2_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-    } else {
-        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_v3_kernel<0>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(flash_attn_fwd_v3_kernel<1>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, p);
-    }
+    hipStream_t st = (hipStream_t)stream;
+#define G3_LAUNCH_ATTN(KERNEL0, KERNEL1) do { if (long_ctx) hipLaunchKernelGGL(KERNEL0, grid, dim3(NTHREADS), smem, st, p); else hipLaunchKernelGGL(KERNEL1, grid, dim3(NTHREADS), smem, st, p); } while (0)
+    // VALU quotas (6, 8) per MFMA measured best of {(4,4), (5,6), (6,8)} (profiles/r1_v5_attn_quota_ab.txt)
+    if (variant == 1) G3_LAUNCH_ATTN(flash_attn_fwd_kernel<0>, flash_attn_fwd_kernel<1>);
+    else if (variant == 2) G3_LAUNCH_ATTN(flash_attn_fwd_v2_kernel<0>, flash_attn_fwd_v2_kernel<1>);
+    else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8>), (flash_attn_fwd_v3_kernel<1, 6, 8>));
+#undef G3_LAUNCH_ATTN
     return g3_check_launch("g3_flash_attn_fwd_bf16");
 }

@@ -96,7 +96,7 @@ def attn_variant(request):
 
 @pytest.mark.parametrize("Sq,Skv,B,H", [(256, 256, 1, 1), (512, 512, 1, 2), (300, 200, 1, 2), (96, 40, 2, 3), (1024, 512, 1, 4),
                                          (2048, 2048, 1, 2), (64, 64, 1, 1), (64, 65, 1, 1), (100, 128, 1, 1), (70, 129, 1, 1),
-                                         (512, 4160, 1, 1)])
+                                         (512, 4160, 1, 1), (128, 192, 1, 1), (128, 250, 1, 1), (128, 320, 1, 2), (64, 449, 1, 1)])
 def test_flash_attn(Sq, Skv, B, H, attn_variant):
     from gen3c_amd import ops
     dev = _dev()
