@@ -281,3 +281,53 @@ class Cache3D_Buffer(Cache3D_Base):
             per_buffer = torch.arange(pixels.shape[2] - 1, -1, -1, device=pixels.device) * self.noise_aug_strength
             pixels = pixels + noise * per_buffer.reshape(1, 1, -1, 1, 1, 1)
         return pixels, masks
+
+
+class Cache3D_BufferSelector(Cache3D_Base):
+    """cache_3d.py:346-421: many source frames on the N axis; per target keeps the `frame_buffer_max` buffers with the
+    largest mask overlap and (mask_for_max_buffer_model) blanks every buffer but the first near-full one per frame.
+    The selection itself is a few reductions over per-(frame, buffer) scalars and stays in torch."""
+
+    def __init__(self, frame_buffer_max=1, mask_for_max_buffer_model: bool = True, mask_full_threshold: float = 0.9, **kwargs):
+        super().__init__(**kwargs)
+        self.frame_buffer_max = max(int(frame_buffer_max), 1)
+        self.mask_for_max_buffer_model = bool(mask_for_max_buffer_model)
+        self.mask_full_threshold = float(mask_full_threshold)
+
+    def update_cache(self, *args, **kwargs):
+        raise NotImplementedError("Cache3D_BufferSelector does not support update_cache")
+
+    @torch.no_grad()
+    def render_cache(self, target_w2cs, target_intrinsics, render_depth: bool = False, start_frame_idx: int = 0):
+        out_dev = target_w2cs.device
+        pixels_all, masks_all = super().render_cache(target_w2cs, target_intrinsics, render_depth, start_frame_idx)
+        B, F, N = pixels_all.shape[:3]
+        if N <= self.frame_buffer_max:
+            pixels_sel, masks_sel = pixels_all, masks_all
+        else:
+            scores = masks_all.sum(dim=(1, 3, 4, 5))  # [B, N]
+            idx = scores.topk(k=min(self.frame_buffer_max, N), dim=1, largest=True, sorted=True).indices
+            pixels_sel = torch.cat([pixels_all[b:b + 1, :, idx[b]] for b in range(B)], dim=0)
+            masks_sel = torch.cat([masks_all[b:b + 1, :, idx[b]] for b in range(B)], dim=0)
+        if self.mask_for_max_buffer_model and not render_depth:
+            m = masks_sel.mean(dim=[3, 4, 5])  # [B, F, k]
+            flat = m.reshape(-1, m.shape[-1])
+            near_full = flat >= self.mask_full_threshold
+            has = near_full.any(dim=1)
+            first = near_full.float().argmax(dim=1)
+            keep = torch.zeros_like(flat)
+            rows = torch.arange(flat.shape[0], device=flat.device)
+            keep[rows[has], first[has]] = 1
+            keep[rows[~has]] = 1
+            keep = keep.reshape(m.shape)[..., None, None, None]
+            pixels_sel = (pixels_sel + 1) * keep - 1
+            masks_sel = masks_sel * keep
+        return pixels_sel.to(out_dev), masks_sel.to(out_dev)
+
+
+class Cache4D(Cache3D_Base):
+    """cache_3d.py:424-433: per-target-frame sources (dynamic video input); rendering is Cache3D_Base's with
+    `start_frame_idx` selecting the source window."""
+
+    def update_cache(self, **kwargs):
+        raise NotImplementedError
