@@ -28,6 +28,7 @@ int g3_check_launch(const char* what);
 extern int g3_opt_gemm_regstage;  // 1: register-staged GEMM even when the direct-to-LDS path applies
 extern int g3_opt_gemm_rowmajor_tiles;  // 1: plain row-major tile order inside an XCD run (A/B); 0: 4-token-tile super-rows
 extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop (no sched_group_barrier pinning) (A/B)
+extern int g3_opt_gemm_pingpong;        // 1 (default): phase-staggered ping-pong kernel for plain K%64==0 GEMMs
 extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }

@@ -19,6 +19,7 @@
 //     the weight panel).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -56,6 +57,56 @@ struct GemmParams {
 
 G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+// ---- epilogue shared by the kernels below. acc[i][j][r]: feature = nw + 32 i + (r & 3) + 8 (r >> 2) + 4 g ; token = mw + 32 j + l31
+template <int EPI>
+G3_DEVICE void store_tile(const GemmParams& p, f32x16 (&acc)[4][2], int mw, int nw, int l31, int g) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = mw + 32 * j + l31;
+        if (m >= p.M) continue;
+        bf16_t* crow = p.C + (int64_t)m * p.ldc;
+        const bf16_t* rrow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS_RESIDUAL) ? (p.R + (int64_t)m * p.ldr) : nullptr;
+        const bf16_t* grow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL)
+                                 ? (p.gate + (int64_t)(m % p.gate_rows) * p.ldg)
+                                 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n = nw + 32 * i + 8 * q4 + 4 * g;
+                if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+                } else if (EPI == EPI_GATED_RESIDUAL) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
+                    // reference order (blocks.py:456): block output is rounded to bf16 by its Linear, then
+                    // gate*out and x+.. ; we keep fp32 until the single final rounding.
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)rv[e] + (float)gv[e] * v[e];
+                } else if (EPI == EPI_BIAS) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)gv[e];
+                } else if (EPI == EPI_BIAS_RESIDUAL) {
+                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + (float)gv[e]) + (float)rv[e];
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
+                *reinterpret_cast<bf16x4*>(crow + n) = o;
+            }
+        }
+    }
 }
 
 // STAGE_GLDS = true : tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no staging VGPRs, no ds_write
@@ -283,52 +334,215 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         __syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) here: tile t+1 has landed for every wave
     }
 
-    // ---- epilogue. acc[i][j][r]: feature = n_w0+32i + (r&3) + 8*(r>>2) + 4*g ; token = m_w0+32j + l31
+    store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong variant of the plain GEMM (no conv, K % 64 == 0) - the default for the DiT linears.
+//
+// Same 256 x 256 x 64 block tile, same 128(feature) x 64(token) wave tile and accumulator layout as the kernel above, but
+// the K loop is cut into 4 PHASES per K tile, one accumulator quadrant (64 features x 32 tokens, 8 MFMAs = 256 MFMA
+// cycles) each, and the two waves that share a SIMD run half a phase apart:
+//
+//     load section : fragment ds_reads of this phase (W half: 8, token half: 4) + ONE half-tile of LDS-DMA (2 per lane)
+//     s_waitcnt vmcnt(8) ; s_barrier
+//     MFMA section : s_setprio 1 ; 8 MFMAs ; s_setprio 0
+//     s_barrier
+//
+// Waves 4..7 execute one extra s_barrier up front, so while waves 0..3 (one per SIMD) are in their MFMA section waves
+// 4..7 are in their load section and vice versa: the 60-180 cycle issue cost of each LDS-DMA instruction and the LDS
+// latency hide behind the other wave's MFMAs instead of stalling the matrix pipe.
+//
+// Operand tiles are staged as HALF-TILES of 128 rows x 64 k (16 KiB: W rows with bit 6 = h, token rows with bit 5 = h),
+// so that they can be retired and restaged one at a time. Half-tiles are numbered q = 4 t + {0: W0, 1: T0, 2: T1, 3: W1}
+// in the order they are needed; phase f = 4 t + P issues q = f + 6 and reads (P0: q = 4t, 4t+1; P1: 4t+2; P2: 4t+3),
+// LDS holds two K tiles (2 x 4 x 16 KiB = 128 KiB), and the vmcnt before a phase's first barrier leaves the 4 newest
+// half-tiles in flight - everything the NEXT phase reads has landed for every wave once that barrier (plus the stagger
+// barrier) is passed; a buffer is restaged no earlier than two phases after its last ds_read.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N> G3_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+G3_DEVICE void wait_vmcnt_rt(int halftiles) {  // tail phases: the number of half-tiles that may stay in flight
+    switch (halftiles) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<2>(); break;
+        case 2: wait_vmcnt<4>(); break;
+        case 3: wait_vmcnt<6>(); break;
+        default: wait_vmcnt<8>(); break;
+    }
+}
+G3_DEVICE void phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [slot 2][region 4][128 rows][64] bf16
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + slot;
+    }
+    int tile_m, tile_n;
+    if (p.tile_order_rowmajor) {
+        tile_m = bid / p.tiles_n;
+        tile_n = bid - tile_m * p.tiles_n;
+    } else {
+        constexpr int GM = 4;
+        const int per_group = GM * p.tiles_n;
+        const int grp = bid / per_group;
+        const int within = bid - grp * per_group;
+        const int gm = min(GM, p.tiles_m - grp * GM);
+        tile_n = within / gm;
+        tile_m = grp * GM + (within - tile_n * gm);
+    }
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int wn = wave & 1;   // feature half of the block tile
+    const int wm = wave >> 1;  // token quarter of the block tile
+    const int n_w0 = wn * 128, m_w0 = wm * 64;
+
+    // ---- LDS-DMA sources. A half-tile is 1024 16-B slots, 2 per lane: slot = j*512 + tid -> local row j*64 + (tid >> 3),
+    // physical chunk tid & 7, which holds logical chunk (tid & 7) ^ ((row >> 1) & 7).
+    //   W half h : local row r <-> feature n0 + (r >> 6)*128 + h*64 + (r & 63)
+    //   T half h : local row r <-> token   m0 + (r >> 5)*64  + h*32 + (r & 31)
+    const int src_chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const bf16_t* src[4][2];  // [region: W0, T0, T1, W1][j]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = m0 + m_w0 + 32 * j + l31;
-        if (m >= p.M) continue;
-        bf16_t* crow = p.C + (int64_t)m * p.ldc;
-        const bf16_t* rrow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS_RESIDUAL) ? (p.R + (int64_t)m * p.ldr) : nullptr;
-        const bf16_t* grow = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL)
-                                 ? (p.gate + (int64_t)(m % p.gate_rows) * p.ldg)
-                                 : nullptr;
+        const int r = j * 64 + (tid >> 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int n = n0 + n_w0 + 32 * i + 8 * q4 + 4 * g;
-                if (n >= p.N) continue;  // N % 4 == 0 is required by the host wrapper
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
-                if (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
-                } else if (EPI == EPI_GATED_RESIDUAL) {
-                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
-                    // reference order (blocks.py:456): block output is rounded to bf16 by its Linear, then
-                    // gate*out and x+.. ; we keep fp32 until the single final rounding.
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (float)rv[e] + (float)gv[e] * v[e];
-                } else if (EPI == EPI_BIAS) {
-                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)gv[e];
-                } else if (EPI == EPI_BIAS_RESIDUAL) {
-                    const bf16x4 gv = *reinterpret_cast<const bf16x4*>(grow + n);
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rrow + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] + (float)gv[e]) + (float)rv[e];
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
-                *reinterpret_cast<bf16x4*>(crow + n) = o;
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int nrow = min(n0 + (r >> 6) * 128 + h * 64 + (r & 63), p.N - 1);
+            const int mrow = min(m0 + (r >> 5) * 64 + h * 32 + (r & 31), p.M - 1);
+            src[h ? 3 : 0][j] = p.W + (int64_t)nrow * p.ldw + src_chunk * 8;
+            src[h ? 2 : 1][j] = p.A + (int64_t)mrow * p.lda + src_chunk * 8;
         }
     }
+    auto issue = [&](int region, int tile) __attribute__((always_inline)) {  // region compile-time after inlining
+        const int k0 = tile * BK;
+        char* dst = smem_raw + ((tile & 1) << 16) + region * 16384 + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[region][j] + k0),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses (bytes inside a slot): row*128 + ((2 ks + g) ^ ((row >> 1) & 7))*16
+    unsigned koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(l31 * 128 + (((2 * ks + g) ^ ((l31 >> 1) & 7)) << 4));
+    const unsigned w_base = (unsigned)(wn * 64 * 128);  // + region*16384 + i*32*128
+    const unsigned t_base = (unsigned)(wm * 32 * 128);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 wf[2][4];  // current W half: [row block][k-step]
+    bf16x8 tf[2][4];  // both token halves: [half][k-step]
+
+    const int nk = p.K / BK;
+    const int nq = 4 * nk;
+
+    auto phase = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        constexpr bool full = decltype(FULL)::value;
+        const char* sl = smem_raw + ((t & 1) << 16);
+        if (P == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    wf[i][ks] = *reinterpret_cast<const bf16x8*>(sl + 0 * 16384 + w_base + i * 4096 + koff[ks]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) tf[0][ks] = *reinterpret_cast<const bf16x8*>(sl + 1 * 16384 + t_base + koff[ks]);
+        } else if (P == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) tf[1][ks] = *reinterpret_cast<const bf16x8*>(sl + 2 * 16384 + t_base + koff[ks]);
+        } else if (P == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    wf[i][ks] = *reinterpret_cast<const bf16x8*>(sl + 3 * 16384 + w_base + i * 4096 + koff[ks]);
+        }
+        const int f = 4 * t + P;
+        if (full) {
+            issue((P + 2) & 3, t + (P < 2 ? 1 : 2));
+            wait_vmcnt<8>();
+        } else {
+            if (f + 6 < nq) issue((P + 2) & 3, t + (P < 2 ? 1 : 2));
+            const int newest = min(f + 6, nq - 1);
+            wait_vmcnt_rt(max(newest - (f + 2), 0));
+        }
+        phase_barrier();
+        constexpr int ih = (P >= 2) ? 2 : 0;
+        constexpr int jh = (P == 1 || P == 2) ? 1 : 0;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[ih + i][jh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], tf[jh][ks], acc[ih + i][jh], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        phase_barrier();
+    };
+
+    // ---- prologue: half-tiles 0..5, the first two landed before anyone reads
+    {
+        const int n0q = min(6, nq);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            if (q < n0q) issue(q & 3, q >> 2);
+        wait_vmcnt_rt(n0q - 2);
+        phase_barrier();
+        if (wave >= 4) phase_barrier();  // stagger: waves 4..7 run half a phase behind waves 0..3
+    }
+    using std::integral_constant;
+    int t = 0;
+    for (; t + 2 < nk; ++t) {
+        phase(integral_constant<int, 0>{}, integral_constant<bool, true>{}, t);
+        phase(integral_constant<int, 1>{}, integral_constant<bool, true>{}, t);
+        phase(integral_constant<int, 2>{}, integral_constant<bool, true>{}, t);
+        phase(integral_constant<int, 3>{}, integral_constant<bool, true>{}, t);
+    }
+    for (; t < nk; ++t) {
+        phase(integral_constant<int, 0>{}, integral_constant<bool, false>{}, t);
+        phase(integral_constant<int, 1>{}, integral_constant<bool, false>{}, t);
+        phase(integral_constant<int, 2>{}, integral_constant<bool, false>{}, t);
+        phase(integral_constant<int, 3>{}, integral_constant<bool, false>{}, t);
+    }
+    if (wave < 4) phase_barrier();
+
+    store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
+}
+
+template <int EPI>
+int launch_pp(const GemmParams& p, hipStream_t stream, const char* what) {
+    const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), smem, stream, p);
+    return g3_check_launch(what);
 }
 
 template <int EPI, bool STAGE_GLDS, bool CONV, bool PIN>
@@ -349,6 +563,9 @@ int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
 template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
+    if constexpr (!CONV) {
+        if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI>(p, stream, what);
+    }
     if (g3_opt_gemm_unpinned) return glds ? launch_variant<EPI, true, CONV, false>(p, stream, what) : launch_variant<EPI, false, CONV, false>(p, stream, what);
     return glds ? launch_variant<EPI, true, CONV, true>(p, stream, what) : launch_variant<EPI, false, CONV, true>(p, stream, what);
 }

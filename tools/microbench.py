@@ -34,11 +34,15 @@ def bench_gemm():
         res_line = []
         for rnd in range(2):
             for variant in (0, 1):
-                ops.set_option("gemm_unpinned", variant)
+                ops.set_option("gemm_pingpong", variant)
                 ms = timeit(lambda: ops.gemm_nt(a, w, out=out, epilogue=epi, **kw), 5)
                 res_line.append((variant, ms, fl / ms / 1e9))
-        ops.set_option("gemm_unpinned", 0)
-        print(f"gemm {name} {M}x{N}x{K} epi{epi}: " + "  ".join(f"[unpinned={v} {ms:.3f}ms {tf:.0f}TF]" for v, ms, tf in res_line), flush=True)
+        ops.set_option("gemm_pingpong", 1)
+        if epi == 0:  # vendor-library yardstick for the plain GEMM (hipBLASLt through torch; not part of the product path)
+            wt = w.t()
+            ms = timeit(lambda: torch.matmul(a, wt, out=out), 5)
+            res_line.append(("blaslt", ms, fl / ms / 1e9))
+        print(f"gemm {name} {M}x{N}x{K} epi{epi}: " + "  ".join(f"[pp={v} {ms:.3f}ms {tf:.0f}TF]" for v, ms, tf in res_line), flush=True)
         del a, w, gate, res, out
 
 
