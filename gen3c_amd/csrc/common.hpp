@@ -28,7 +28,8 @@ int g3_check_launch(const char* what);
 extern int g3_opt_gemm_regstage;  // 1: register-staged GEMM even when the direct-to-LDS path applies
 extern int g3_opt_gemm_rowmajor_tiles;  // 1: plain row-major tile order inside an XCD run (A/B); 0: 4-token-tile super-rows
 extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop (no sched_group_barrier pinning) (A/B)
-extern int g3_opt_gemm_pingpong;        // 1 (default): phase-staggered ping-pong kernel for plain K%64==0 GEMMs
+extern int g3_opt_gemm_pingpong;        // plain K%64==0 GEMMs: 2 (default) / 1 = phase-staggered ping-pong kernel with 2 / 4 phases per K tile, 0 = classic
+extern int g3_opt_gemm_wide_store;      // 1 (default): LDS-transposed full-line epilogue when the operands allow 16-byte rows
 extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }
@@ -44,16 +45,20 @@ G3_DEVICE bf16x8 zero_bf16x8() {
 G3_DEVICE float wave_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 
 G3_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below one bf16 ulp of the GELU output): 1 rcp + 1 exp + 6 fma
-// instead of libm's ~40-instruction erff in a GEMM epilogue that evaluates it 128 times per lane.
+// GELU(x) = x * Phi(x) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below one bf16 ulp of the output),
+// folded so that no sign handling is left:  with z = |x|/sqrt2, t = 1/(1 + p z), q = poly(t) t exp(-z^2) = 1 - erf(z):
+//   x >= 0: 0.5 x (2 - q) = x - 0.5 |x| q ;   x < 0: 0.5 x q = -0.5 |x| q      =>   GELU(x) = max(x, 0) - 0.5 |x| q.
+// 1 rcp + 1 exp2 + 12 VALU (the 0.5 lives in the coefficients) instead of libm's ~40-instruction erff, in a GEMM epilogue
+// that evaluates it 128 times per lane.
 G3_DEVICE float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = __builtin_fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.5f * 0.254829592f);
+    const float ex = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));  // exp(-z^2), z^2 = x^2 / 2
+    const float a = ((poly * t) * ex) * ax;
+    return fmaxf(x, 0.0f) - a;
 }
 G3_DEVICE float silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -45,6 +45,7 @@ __device__ __attribute__((aligned(16))) unsigned g3_zero_page[64];  // 256 zero 
 
 struct GemmParams {
     int tile_order_rowmajor;
+    int wide_store;  // C / residual / gate rows are 16-byte addressable: epilogue goes through the LDS transpose (full-line stores)
     const bf16_t* A; int64_t lda;
     const bf16_t* W; int64_t ldw;
     bf16_t* C; int64_t ldc;
@@ -105,6 +106,68 @@ G3_DEVICE void store_tile(const GemmParams& p, f32x16 (&acc)[4][2], int mw, int 
                 for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
                 *reinterpret_cast<bf16x4*>(crow + n) = o;
             }
+        }
+    }
+}
+
+// Full-line epilogue: the MFMA layout gives a lane 4 features of 32 different token rows, so direct stores touch 32 cache
+// lines with 16 bytes each per instruction (measured ~2.5 TB/s of C traffic). Instead each wave transposes its tile through
+// a PRIVATE 16 KiB slice of the (now idle) operand LDS, one 32-token half at a time, as fp32 [32 tokens][128 features]
+// with the 16-byte chunk index XOR-ed by the row, and reads it back row-major: a lane then owns 8 consecutive features
+// (one 16-byte bf16 store), 16 lanes cover a token row's 256 bytes, and residual/gate loads coalesce the same way.
+// No barrier: LDS operations of one wave execute in order and the slice is not shared. Same arithmetic as store_tile.
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+template <int EPI>
+G3_DEVICE void store_tile_lds(const GemmParams& p, f32x16 (&acc)[4][2], int mw, int nw, int lane, char* stage) {
+    const int l31 = lane & 31, g = lane >> 5;
+    const int rsub = lane >> 4, c2 = lane & 15;
+    const int n = nw + 8 * c2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                *reinterpret_cast<f32x4*>(stage + l31 * 512 + (((8 * i + 2 * q4 + g) ^ l31) << 4)) = v;
+            }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int row = 4 * s + rsub;
+            const int m = mw + 32 * j + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 512 + (((2 * c2) ^ row) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 512 + (((2 * c2 + 1) ^ row) << 4));
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = lo[e];
+                v[4 + e] = hi[e];
+            }
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+            } else if (EPI != EPI_NONE) {
+                const bf16x8 gv = load_bf16x8(p.gate + (int64_t)(p.gate_rows == 1 ? 0 : m % p.gate_rows) * p.ldg + n);
+                if (EPI == EPI_GATED_RESIDUAL) {
+                    const bf16x8 rv = load_bf16x8(p.R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)rv[e] + (float)gv[e] * v[e];
+                } else if (EPI == EPI_BIAS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)gv[e];
+                } else if (EPI == EPI_BIAS_RESIDUAL) {
+                    const bf16x8 rv = load_bf16x8(p.R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (v[e] + (float)gv[e]) + (float)rv[e];
+                }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
+            store_bf16x8(p.C + (int64_t)m * p.ldc + n, o);
         }
     }
 }
@@ -334,7 +397,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         __syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) here: tile t+1 has landed for every wave
     }
 
-    store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
+    if (p.wide_store) store_tile_lds<EPI>(p, acc, m0 + m_w0, n0 + n_w0, lane, smem_raw + wave * 16384);
+    else store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
 }
 
 
@@ -377,7 +441,7 @@ G3_DEVICE void phase_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI>
+template <int EPI, int PH>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [slot 2][region 4][128 rows][64] bf16
     const int tid = threadIdx.x;
@@ -459,27 +523,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     const int nk = p.K / BK;
     const int nq = 4 * nk;
 
-    auto phase = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
+    auto read_w = [&](const char* sl, int region) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                wf[i][ks] = *reinterpret_cast<const bf16x8*>(sl + region * 16384 + w_base + i * 4096 + koff[ks]);
+    };
+    auto read_t = [&](const char* sl, int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) tf[h][ks] = *reinterpret_cast<const bf16x8*>(sl + (1 + h) * 16384 + t_base + koff[ks]);
+    };
+
+    // PH == 4: one accumulator quadrant (8 MFMAs) per phase, one half-tile issued per phase.
+    auto phase4 = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
         constexpr bool full = decltype(FULL)::value;
         const char* sl = smem_raw + ((t & 1) << 16);
         if (P == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    wf[i][ks] = *reinterpret_cast<const bf16x8*>(sl + 0 * 16384 + w_base + i * 4096 + koff[ks]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) tf[0][ks] = *reinterpret_cast<const bf16x8*>(sl + 1 * 16384 + t_base + koff[ks]);
+            read_w(sl, 0);
+            read_t(sl, 0);
         } else if (P == 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) tf[1][ks] = *reinterpret_cast<const bf16x8*>(sl + 2 * 16384 + t_base + koff[ks]);
+            read_t(sl, 1);
         } else if (P == 2) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    wf[i][ks] = *reinterpret_cast<const bf16x8*>(sl + 3 * 16384 + w_base + i * 4096 + koff[ks]);
+            read_w(sl, 3);
         }
         const int f = 4 * t + P;
         if (full) {
@@ -502,46 +569,102 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
         __builtin_amdgcn_s_setprio(0);
         phase_barrier();
     };
+    // PH == 2: one W half x both token halves (16 MFMAs) per phase, two half-tiles issued per phase. A buffer is restaged
+    // one phase after its last read here, which is safe because the reads are retired (lgkmcnt(0)) BEFORE the reading
+    // phase's first barrier - also for the wave group that runs a barrier behind.
+    auto phase2 = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        constexpr bool full = decltype(FULL)::value;
+        const char* sl = smem_raw + ((t & 1) << 16);
+        if (P == 0) {
+            read_w(sl, 0);
+            read_t(sl, 0);
+            read_t(sl, 1);
+        } else {
+            read_w(sl, 3);
+        }
+        const int q0 = 4 * t + (P == 0 ? 6 : 8);     // first of the two half-tiles this phase issues
+        const int need = 4 * t + (P == 0 ? 3 : 6);   // newest half-tile the NEXT phase reads
+        if (full) {
+            issue(P == 0 ? 2 : 0, t + (P == 0 ? 1 : 2));
+            issue(P == 0 ? 3 : 1, t + (P == 0 ? 1 : 2));
+            wait_vmcnt<(P == 0 ? 8 : 6)>();
+        } else {
+            if (q0 < nq) {
+                issue(P == 0 ? 2 : 0, t + (P == 0 ? 1 : 2));
+                issue(P == 0 ? 3 : 1, t + (P == 0 ? 1 : 2));
+            }
+            const int newest = min(q0 + 1, nq - 1);
+            wait_vmcnt_rt(max(newest - need, 0));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        phase_barrier();
+        constexpr int ih = P * 2;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], tf[j][ks], acc[ih + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        phase_barrier();
+    };
 
-    // ---- prologue: half-tiles 0..5, the first two landed before anyone reads
+    // ---- prologue: half-tiles 0..5; what the first phase reads has landed before anyone starts
     {
         const int n0q = min(6, nq);
 #pragma unroll
         for (int q = 0; q < 6; ++q)
             if (q < n0q) issue(q & 3, q >> 2);
-        wait_vmcnt_rt(n0q - 2);
+        wait_vmcnt_rt(n0q - (PH == 4 ? 2 : 3));
         phase_barrier();
         if (wave >= 4) phase_barrier();  // stagger: waves 4..7 run half a phase behind waves 0..3
     }
     using std::integral_constant;
+    using T_ = integral_constant<bool, true>;
+    using F_ = integral_constant<bool, false>;
     int t = 0;
-    for (; t + 2 < nk; ++t) {
-        phase(integral_constant<int, 0>{}, integral_constant<bool, true>{}, t);
-        phase(integral_constant<int, 1>{}, integral_constant<bool, true>{}, t);
-        phase(integral_constant<int, 2>{}, integral_constant<bool, true>{}, t);
-        phase(integral_constant<int, 3>{}, integral_constant<bool, true>{}, t);
-    }
-    for (; t < nk; ++t) {
-        phase(integral_constant<int, 0>{}, integral_constant<bool, false>{}, t);
-        phase(integral_constant<int, 1>{}, integral_constant<bool, false>{}, t);
-        phase(integral_constant<int, 2>{}, integral_constant<bool, false>{}, t);
-        phase(integral_constant<int, 3>{}, integral_constant<bool, false>{}, t);
+    if (PH == 4) {
+        for (; t + 2 < nk; ++t) {
+            phase4(integral_constant<int, 0>{}, T_{}, t);
+            phase4(integral_constant<int, 1>{}, T_{}, t);
+            phase4(integral_constant<int, 2>{}, T_{}, t);
+            phase4(integral_constant<int, 3>{}, T_{}, t);
+        }
+        for (; t < nk; ++t) {
+            phase4(integral_constant<int, 0>{}, F_{}, t);
+            phase4(integral_constant<int, 1>{}, F_{}, t);
+            phase4(integral_constant<int, 2>{}, F_{}, t);
+            phase4(integral_constant<int, 3>{}, F_{}, t);
+        }
+    } else {
+        for (; t + 2 < nk; ++t) {
+            phase2(integral_constant<int, 0>{}, T_{}, t);
+            phase2(integral_constant<int, 1>{}, T_{}, t);
+        }
+        for (; t < nk; ++t) {
+            phase2(integral_constant<int, 0>{}, F_{}, t);
+            phase2(integral_constant<int, 1>{}, F_{}, t);
+        }
     }
     if (wave < 4) phase_barrier();
 
-    store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
+    if (p.wide_store) store_tile_lds<EPI>(p, acc, m0 + m_w0, n0 + n_w0, lane, smem_raw + wave * 16384);
+    else store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
 }
 
-template <int EPI>
+template <int EPI, int PH>
 int launch_pp(const GemmParams& p, hipStream_t stream, const char* what) {
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_pp_kernel<EPI, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), smem, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<EPI, PH>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), smem, stream, p);
     return g3_check_launch(what);
 }
 
@@ -564,7 +687,8 @@ template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
     if constexpr (!CONV) {
-        if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI>(p, stream, what);
+        if (glds && g3_opt_gemm_pingpong == 2) return launch_pp<EPI, 2>(p, stream, what);
+        if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI, 4>(p, stream, what);
     }
     if (g3_opt_gemm_unpinned) return glds ? launch_variant<EPI, true, CONV, false>(p, stream, what) : launch_variant<EPI, false, CONV, false>(p, stream, what);
     return glds ? launch_variant<EPI, true, CONV, true>(p, stream, what) : launch_variant<EPI, false, CONV, true>(p, stream, what);
@@ -589,6 +713,8 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
+    p.wide_store = g3_opt_gemm_wide_store && !(N & 7) && !(ldc & 7) && !((uintptr_t)C & 15) &&
+                   (!gate || (!(ldg & 7) && !((uintptr_t)gate & 15))) && (!residual || (!(ldr & 7) && !((uintptr_t)residual & 15)));
     p.cv = ConvGeom{};
     hipStream_t s = (hipStream_t)stream;
     const char* what = "g3_gemm_bf16_nt";
@@ -632,6 +758,8 @@ extern "C" int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, i
     p.R = (const bf16_t*)residual; p.ldr = ldr;
     p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
+    p.wide_store = g3_opt_gemm_wide_store && !(N & 7) && !(ld_out & 7) && !((uintptr_t)out & 15) && (!bias || !((uintptr_t)bias & 15)) &&
+                   (!residual || (!(ldr & 7) && !((uintptr_t)residual & 15)));
     p.cv = ConvGeom{To, Ho, Wo, Ti, Hi, Wi, kt, kh, kw, st, sh, sw, ot, oh, ow, kt * kh * kw, (int64_t)N * ldw};
     hipStream_t s = (hipStream_t)stream;
     const char* what = "g3_conv3d_cl_bf16";

@@ -30,15 +30,19 @@ def _report(name, got, ref):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 260, 136), (1000, 64, 328), (56, 1024, 4096),
                                    (2048, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("regstage", [0, 1, 2])
+@pytest.mark.parametrize("regstage", [0, 1, 2, 3, 4])
 def test_gemm_nt(M, N, K, epi, regstage):
     from gen3c_amd import ops
     dev = _dev()
-    # regstage: 0 = LDS-DMA staging (default), 1 = register staging, 2 = ping-pong kernel (the default for K % 64 == 0)
+    # regstage: 0 = LDS-DMA staging (default), 1 = register staging, 2 / 3 = ping-pong kernel with 4 / 2 phases per K tile
     if regstage >= 1 and K % 64 != 0:
         pytest.skip("K % 64 != 0 always takes the register-staged path")
+    # 4 = the default kernel with the direct 8-byte-per-lane epilogue instead of the LDS-transposed full-line one
+    ops.set_option("gemm_wide_store", 0 if regstage == 4 else 1)
+    if regstage == 4:
+        regstage = 3
     ops.set_option("gemm_regstage", 1 if regstage == 1 else 0)
-    ops.set_option("gemm_pingpong", 1 if regstage == 2 else 0)
+    ops.set_option("gemm_pingpong", regstage - 1 if regstage >= 2 else 0)
     g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K + epi)
     a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
@@ -58,7 +62,8 @@ def test_gemm_nt(M, N, K, epi, regstage):
         out = ops.gemm_nt(a, w)
     torch.cuda.synchronize()
     ops.set_option("gemm_regstage", 0)
-    ops.set_option("gemm_pingpong", 1)
+    ops.set_option("gemm_pingpong", 2)
+    ops.set_option("gemm_wide_store", 1)
     _report(f"gemm {M}x{N}x{K} epi{epi} regstage{regstage}", out, ref)
     # one bf16 rounding of the output (2^-8 relative worst case) + fp32 accumulation noise
     torch.testing.assert_close(out.float(), ref, rtol=1.0 / 128, atol=2e-2)
