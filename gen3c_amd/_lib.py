@@ -38,6 +38,8 @@ SIGNATURES = {
     "g3_mesh_occlusion_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "g3_unproject_points_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "g3_reliable_depth_mask_f32": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
+    "g3_align_depth_workspace_bytes": [i32, i32],
+    "g3_align_depth_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, C.c_size_t, i32, i32, vp],
     "g3_conv3d_cl_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64] + [i32] * 17 + [vp],
     "g3_groupnorm_swish_cl_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
     "g3_haar3d_patch_bf16": [vp, vp, i32, i32, i32, vp],
@@ -49,7 +51,7 @@ SIGNATURES = {
     "g3_edm_prepare_input_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, vp],
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }
-_RESTYPES = {"g3_last_error": C.c_char_p}
+_RESTYPES = {"g3_last_error": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t}
 
 
 class Gen3cHipError(RuntimeError):

@@ -100,3 +100,43 @@ def generate_camera_trajectory(trajectory_type: str, initial_w2c: torch.Tensor, 
     else:
         Ks = initial_intrinsics.unsqueeze(0)
     return w2cs, Ks
+
+
+def align_depth(source_depth: torch.Tensor, target_depth: torch.Tensor, target_mask: torch.Tensor | None, k: torch.Tensor | None = None,
+                c2w: torch.Tensor | None = None, alignment_method: str = "rigid", num_iters: int = 100, lambda_arap: float = 0.1,
+                smoothing_kernel_size: int = 3) -> torch.Tensor:
+    """Align a predicted (H, W) depth map to the depth rendered from the 3D cache (camera_utils.py:275-345).
+
+    "rigid": affine fit in inverse depth after 10 %/90 % quantile outlier rejection (:225-272); "non_rigid": additionally
+    `num_iters` Adam steps on a per-pixel scale map (data loss on unprojected points inside target_mask + lambda_arap * 3x3
+    ARAP smoothness). One HIP library call on the current stream (csrc/align.hip); fp32; inputs must live on the GPU."""
+    from . import _lib
+    if alignment_method not in ("rigid", "non_rigid"):
+        raise NotImplementedError(alignment_method)
+    if source_depth.dim() != 2 or source_depth.shape != target_depth.shape:
+        raise ValueError("align_depth expects (H, W) source and target depth maps of the same shape")
+    non_rigid = alignment_method == "non_rigid"
+    if non_rigid and (k is None or c2w is None):
+        raise ValueError("Camera intrinsics (k) and camera-to-world matrix (c2w) are required for non-rigid alignment")
+    if non_rigid and smoothing_kernel_size != 3:
+        raise NotImplementedError("the HIP ARAP term is the reference's default 3x3 box (smoothing_kernel_size=3)")
+    dev = source_depth.device
+    H, W = source_depth.shape
+    src = source_depth.detach().to(torch.float32).contiguous()
+    tgt = target_depth.detach().to(dev, torch.float32).contiguous()
+    msk = None if target_mask is None else (target_mask.to(dev) > 0).to(torch.uint8).contiguous()
+    out = torch.empty_like(src)
+    lib = _lib.load()
+    nbytes = lib.g3_align_depth_workspace_bytes(H, W)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+    import ctypes as C
+    kinv_p = t_p = None
+    if non_rigid:
+        kinv = torch.linalg.inv(k.detach().to("cpu", torch.float32)).contiguous()
+        tmat = torch.linalg.inv(c2w.detach().to("cpu", torch.float32))[:3].contiguous()  # unproject_points inverts its "w2c" argument
+        kinv_p, t_p = C.c_void_p(kinv.data_ptr()), C.c_void_p(tmat.data_ptr())
+    _lib.check(lib.g3_align_depth_f32(src.data_ptr(), tgt.data_ptr(), None if msk is None else msk.data_ptr(), kinv_p, t_p,
+                                      int(non_rigid), int(num_iters), float(lambda_arap), 1e-3, out.data_ptr(), ws_ptr, nbytes, H, W,
+                                      torch.cuda.current_stream(dev).cuda_stream), "g3_align_depth_f32")
+    return out

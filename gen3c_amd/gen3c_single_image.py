@@ -33,7 +33,7 @@ def create_parser() -> argparse.ArgumentParser:
     p.add_argument("--num_gpus", type=int, default=1)
     p.add_argument("--guidance", type=float, default=1.0)
     p.add_argument("--num_steps", type=int, default=35)
-    p.add_argument("--num_video_frames", type=int, default=121)
+    p.add_argument("--num_video_frames", type=int, default=None, help="N*120+1 (default 121); N > 1 runs autoregressive chunks")
     p.add_argument("--height", type=int, default=704)
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--fps", type=int, default=24)
@@ -45,6 +45,10 @@ def create_parser() -> argparse.ArgumentParser:
     p.add_argument("--noise_aug_strength", type=float, default=0.0)
     p.add_argument("--filter_points_threshold", type=float, default=0.05)
     p.add_argument("--foreground_masking", action="store_true")
+    p.add_argument("--ar_depth", type=str, default="cache",
+                   help="depth for the last frame of each autoregressive chunk (the reference runs MoGe, which is not available "
+                        "offline): 'cache' = depth rendered from the 3D cache at that camera with holes filled by the median, or "
+                        "'module:function' naming a callable image[3,H,W] in [0,1] -> (depth[1,1,H,W], mask[1,1,H,W] or None)")
     p.add_argument("--random_init", action="store_true", help="random weights instead of checkpoints (plumbing tests)")
     p.add_argument("--tiny", action="store_true", help="with --random_init: a small DiT/tokenizer and a 9-frame chunk (plumbing tests)")
     return p
@@ -56,6 +60,22 @@ def _load_image(path: str, H: int, W: int) -> torch.Tensor:
     return torch.from_numpy(np.asarray(img).astype(np.float32))  # [H,W,3] 0..255
 
 
+def _resolve_depth_fn(spec: str, cache):
+    """-> callable(image[3,H,W] in [0,1], w2c[1,4,4], K[1,3,3]) -> (depth[1,1,H,W], mask or None). Stands in for
+    _predict_moge_depth_from_tensor (gen3c_single_image.py:183-229); user callables take the image only, like MoGe."""
+    if spec == "cache":
+        def from_cache(_image, w2c, K):
+            d, m = cache.render_cache(w2c[:, None], K[:, None], render_depth=True)
+            d, m = d[:, 0, 0], m[:, 0, 0, 0] > 0                                   # newest buffer: [1,H,W]
+            fill = d[m].median() if bool(m.any()) else d.new_tensor(1.0)
+            return torch.where(m, d, fill)[:, None], None
+        return from_cache
+    mod, _, fn = spec.partition(":")
+    import importlib
+    user = getattr(importlib.import_module(mod), fn)
+    return lambda image, _w2c, _K: user(image)
+
+
 def demo(args) -> np.ndarray:
     from gen3c_amd import renderer
     from gen3c_amd.camera_utils import generate_camera_trajectory
@@ -64,9 +84,12 @@ def demo(args) -> np.ndarray:
     from gen3c_amd.pipeline import DiffusionGen3CModel, Gen3cPipeline
     from gen3c_amd.tokenizer import VideoTokenizer
 
-    assert args.num_video_frames is not None and (args.num_video_frames - 1) % 120 == 0, "num_video_frames must be N*120+1"
-    if args.num_video_frames != 121:
-        raise NotImplementedError("autoregressive chunks (update_cache + depth alignment) are not built yet; use --num_video_frames 121")
+    tiny = args.tiny and args.random_init
+    step_frames = 8 if tiny else 120
+    if args.num_video_frames is None:
+        args.num_video_frames = step_frames + 1
+    assert (args.num_video_frames - 1) % step_frames == 0, \
+        f"num_video_frames must be N*{step_frames}+1"   # gen3c_single_image.py:112
     local = 0
     if args.num_gpus > 1:
         local = init_distributed("nccl")
@@ -74,7 +97,7 @@ def demo(args) -> np.ndarray:
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     H, W = args.height, args.width
-    chunk = 9 if (args.tiny and args.random_init) else 121
+    chunk = step_frames + 1
 
     # ---- models
     if args.random_init and args.tiny:
@@ -121,8 +144,8 @@ def demo(args) -> np.ndarray:
     center_depth = float(torch.quantile(valid.flatten()[:: max(1, valid.numel() // 100000)], 0.5)) if valid.numel() else 1.0
     traj = "left" if args.trajectory == "none" else args.trajectory
     dist_ = 0.0 if args.trajectory == "none" else args.movement_distance
-    w2cs, Ks = generate_camera_trajectory(traj, w2c0, K, chunk, dist_, args.camera_rotation, center_depth=center_depth, device=dev)
-    renders, masks = cache.render_cache(w2cs, Ks)
+    w2cs, Ks = generate_camera_trajectory(traj, w2c0, K, args.num_video_frames, dist_, args.camera_rotation, center_depth=center_depth, device=dev)
+    renders, masks = cache.render_cache(w2cs[:, :chunk], Ks[:, :chunk])
 
     def emb(path):
         if path is None:
@@ -132,6 +155,18 @@ def demo(args) -> np.ndarray:
     cond_image = (img255.permute(2, 0, 1) / 128.0 - 1.0)[None, :, None].to(torch.bfloat16)   # condition image uses x/128-1 (inference_utils.py:648)
     neg = emb(args.negative_t5_embedding_path) if args.negative_t5_embedding_path else None
     video = pipe.generate(emb(args.t5_embedding_path), cond_image, renders, masks, negative_prompt_embedding=neg)
+
+    # ---- autoregressive chunks (gen3c_single_image.py:378-419): last frame -> depth -> aligned cache update -> next 121 frames
+    depth_fn = _resolve_depth_fn(args.ar_depth, cache)
+    for it in range(1, (args.num_video_frames - 1) // (chunk - 1)):
+        start = it * (chunk - 1)  # chunks overlap by one frame
+        pred01 = torch.from_numpy(video[-1]).to(dev).permute(2, 0, 1).to(torch.float32) / 255.0
+        pred_depth, pred_mask = depth_fn(pred01, w2cs[:, start], Ks[:, start])
+        cache.update_cache(new_image=pred01[None] * 2 - 1, new_depth=pred_depth, new_w2c=w2cs[:, start], new_intrinsics=Ks[:, start])
+        renders, masks = cache.render_cache(w2cs[:, start:start + chunk], Ks[:, start:start + chunk])
+        cond = (pred01[None, :, None] * 2 - 1).to(torch.bfloat16)
+        video_new = pipe.generate(emb(args.t5_embedding_path), cond, renders, masks, negative_prompt_embedding=neg)
+        video = np.concatenate([video, video_new[1:]], axis=0)
 
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:  # the reference lets every rank write the same file (gen3c_single_image.py:469-476); one writer suffices

@@ -245,10 +245,21 @@ class Cache3D_Buffer(Cache3D_Base):
     @torch.no_grad()
     def update_cache(self, new_image, new_depth, new_w2c, new_mask=None, new_intrinsics=None, depth_alignment=True,
                      alignment_method="non_rigid"):
-        if depth_alignment:
-            raise NotImplementedError("depth alignment (camera_utils.align_depth) is the autoregressive row (SURVEY 8f-1), not built yet")
         new_image = new_image.to(self.device, f32)
         new_depth = torch.clamp(torch.nan_to_num(new_depth.to(self.device, f32), nan=1e4), min=0, max=1e4)
+        if depth_alignment:  # cache_3d.py:256-292: agree with what the cache already shows from the new camera
+            from .camera_utils import align_depth
+            if alignment_method not in ("rigid", "non_rigid"):
+                raise NotImplementedError(alignment_method)
+            w2c_d, k_d = new_w2c.to(self.device, f32), new_intrinsics.to(self.device, f32)
+            target_depth, target_mask = self.render_cache(w2c_d.unsqueeze(1), k_d.unsqueeze(1), render_depth=True)
+            target_depth, target_mask = target_depth[:, :, 0].squeeze(), target_mask[:, :, 0].squeeze()
+            assert target_depth.dim() == 2, "depth alignment handles one image (B = 1), as the reference's squeeze() does"
+            kw = {}
+            if alignment_method == "non_rigid":
+                kw = dict(k=k_d.squeeze(), c2w=_host_inverse(w2c_d.squeeze()), alignment_method="non_rigid", num_iters=100,
+                          lambda_arap=0.1, smoothing_kernel_size=3)
+            new_depth = align_depth(new_depth.squeeze(), target_depth, target_mask.bool(), **kw).reshape_as(new_depth)
         new_points = unproject_points(new_depth, new_w2c.to(self.device, f32), new_intrinsics.to(self.device, f32))
         B, F, N, V, C, H, W = self.input_image.shape
         if self.filter_points_threshold < 1.0:

@@ -16,6 +16,7 @@
 #ifndef GEN3C_HIP_H
 #define GEN3C_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -131,6 +132,17 @@ int g3_unproject_points_f32(const float* depth, const float* c2w, const float* K
                             void* stream);
 int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int n, int h, int w, int window, float ratio_thresh,
                                float eps, void* stream);
+/* autoregressive cache update: camera_utils.align_depth (camera_utils.py:225-345) for one [H][W] fp32 depth map, enqueued on
+ * `stream` without host synchronisation. Rigid part: 10 %/90 % quantile outlier rejection (torch.quantile 'linear' rank
+ * arithmetic) + affine fit in inverse depth. non_rigid != 0 adds `num_iters` Adam steps (lr, betas 0.9/0.999, eps 1e-8) on a
+ * per-pixel scale map with the reference's data + lambda_arap * 3x3-ARAP loss; T_host = first three rows of inv(c2w) (12
+ * floats - unproject_points inverts what align_depth passes in its w2c slot) and Kinv_host = inverse(K) (9 floats) are HOST
+ * pointers, read at call time. target_mask: u8 [H][W] or NULL (= all pixels). out_depth may not alias the inputs.
+ * workspace: device memory, 256-byte aligned, at least g3_align_depth_workspace_bytes(H, W) bytes. */
+size_t g3_align_depth_workspace_bytes(int H, int W);
+int g3_align_depth_f32(const float* source_depth, const float* target_depth, const uint8_t* target_mask, const float* Kinv_host,
+                       const float* T_host, int non_rigid, int num_iters, float lambda_arap, float lr, float* out_depth,
+                       void* workspace, size_t workspace_bytes, int H, int W, void* stream);
 
 /* ---- causal video tokenizer (Cosmos-Tokenize1-CV8x8x8; tokenizer/modules/{layers3d,patching,utils}.py) ---------------
  * Activations are channels-last bf16 [T][H][W][C] for one batch item.

@@ -45,3 +45,48 @@ def test_buffer_selector_topk_and_exclusive_mask():
     # top-2 by overlap are buffers 0 (full) and 1 (half); buffer 0 is near-full, so buffer 1 is blanked in every frame
     assert torch.all(cover[:, 0] > 0.95) and torch.all(cover[:, 1] == 0)
     assert torch.all(pix[0, :, 1] == -1)
+
+
+def test_update_cache_aligns_new_depth_to_the_cache():
+    """Cache3D_Buffer.update_cache(depth_alignment=True) (cache_3d.py:246-316): a mis-scaled monocular depth for the new frame is
+    pulled onto the geometry the cache already holds; the buffer grows newest-first up to frame_buffer_max."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    H, W = 48, 64
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = (2.0 + 0.004 * xs + 0.002 * ys).to(dev)
+    img = (torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]], device=dev)
+    eye = torch.eye(4, device=dev)
+    for method in ("rigid", "non_rigid"):
+        cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=img, input_depth=depth[None, None], input_w2c=eye[None],
+                                        input_intrinsics=K[None], filter_points_threshold=0.05, input_format=["B", "C", "H", "W"])
+        w2c_new = eye.clone()
+        w2c_new[0, 3] = -0.05  # camera moved 5 cm to the right
+        wrong = 1.0 / (0.6 / depth + 0.05)  # affine-in-inverse-depth distortion, ~1.5x too far
+        cache.update_cache(new_image=img, new_depth=wrong[None, None], new_w2c=w2c_new[None], new_intrinsics=K[None], alignment_method=method)
+        assert cache.input_image.shape[2] == 2 and cache.input_points.shape[2] == 2
+        z_new = cache.input_points[0, 0, 0, 0, ..., 2]      # newest first; world z == camera z for this pure x-translation
+        m = cache.input_mask[0, 0, 0, 0, 0] > 0
+        rel = (z_new[m] / depth[m] - 1).abs()
+        print(f"[update_cache {method}] aligned depth vs scene: max rel {float(rel.max()):.3e} (unaligned {float((wrong / depth - 1).abs().max()):.2f})")
+        assert float(rel.max()) < 0.02
+        cache.update_cache(new_image=img, new_depth=wrong[None, None], new_w2c=w2c_new[None], new_intrinsics=K[None], alignment_method=method)
+        assert cache.input_image.shape[2] == 2  # full buffer: slot 0 is overwritten
+
+
+def test_gen3c_single_image_cli_autoregressive_tiny(tmp_path):
+    """Two autoregressive chunks (8*2+1 frames with the tiny models): chunks overlap by one frame, the cache is updated with the
+    last generated frame + aligned depth, the second chunk is conditioned on that frame (gen3c_single_image.py:378-419)."""
+    from PIL import Image
+    from gen3c_amd import gen3c_single_image as cli
+    H, W = 64, 96
+    ys, xs = np.mgrid[0:H, 0:W]
+    Image.fromarray(np.stack([(xs * 2) % 256, (ys * 3) % 256, ((xs + ys) * 2) % 256], -1).astype(np.uint8)).save(tmp_path / "in.png")
+    np.savez(tmp_path / "depth.npz", depth=(2.0 + 0.01 * xs).astype(np.float32), intrinsics=np.array([[80, 0, W / 2], [0, 80, H / 2], [0, 0, 1]], np.float32))
+    args = cli.create_parser().parse_args([
+        "--input_image_path", str(tmp_path / "in.png"), "--depth_path", str(tmp_path / "depth.npz"), "--height", str(H), "--width", str(W),
+        "--num_steps", "2", "--random_init", "--tiny", "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "ar",
+        "--num_video_frames", "17", "--trajectory", "left"])
+    video = cli.demo(args)
+    assert video.shape == (17, H, W, 3) and video.dtype == np.uint8
