@@ -101,7 +101,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        local = init_distributed("nccl")
+        # G3_BENCH_BACKEND=gloo + G3_BENCH_SHARE_GPU=1: plumbing check of this script's N>1 path on a 1-GPU box (all ranks on
+        # cuda:0, collectives over gloo); not a measurement. The driver's runs use the defaults: RCCL, one GPU per rank.
+        local = init_distributed(os.environ.get("G3_BENCH_BACKEND", "nccl"))
+        if os.environ.get("G3_BENCH_SHARE_GPU") == "1":
+            local = 0
+        torch.cuda.set_device(local)
         parallel_state.initialize_model_parallel(context_parallel_size=world)
     else:
         local = 0

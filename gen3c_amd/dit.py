@@ -395,13 +395,19 @@ class VideoExtendGeneralDIT(nn.Module):
             # -- self attention
             shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
             h = ops.layernorm_modulate(xs, shift, scale)
-            qkv = ops.gemm_nt(h, blk["fa_qkv"])  # [S*B, 3D]
-            q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH)
-            k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH)
-            v = qkv[:, 2 * D:]
             if self._cp_attn is not None:
-                o = self._cp_attn(q, k, v, S, B, nH)
+                # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
+                # every output element sees the same K order, so this is bit-identical to the single fused GEMM)
+                kv = ops.gemm_nt(h, blk["fa_qkv"][D:])  # [S*B, 2D]
+                k = ops.qk_rmsnorm_rope(kv[:, :D], blk["fa_kn"], cos, sin, S, B, nH)
+                pending = self._cp_attn.start(k, kv[:, D:], S, B, nH)
+                q = ops.qk_rmsnorm_rope(ops.gemm_nt(h, blk["fa_qkv"][:D]), blk["fa_qn"], cos, sin, S, B, nH)
+                o = self._cp_attn.finish(q, pending)
             else:
+                qkv = ops.gemm_nt(h, blk["fa_qkv"])  # [S*B, 3D]
+                q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH)
+                k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH)
+                v = qkv[:, 2 * D:]
                 vt = ops.transpose_v(v, S, B, nH)
                 o = ops.flash_attn(q, k, vt, S, S, B, nH)
             ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)

@@ -161,7 +161,9 @@ class ContextParallelAttention:
         self.head_groups = head_groups
         self.backend = backend
 
-    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int) -> torch.Tensor:
+    def start(self, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int):
+        """Issue the K / V all-gathers of every head group (async). Call as soon as K and V exist: whatever the caller
+        launches before finish() - the Q projection and its norm/RoPE in the DiT - hides part of the first group's exchange."""
         be = self.backend or _default_backend()
         G = self.head_groups
         while H % G != 0:
@@ -169,8 +171,6 @@ class ContextParallelAttention:
         Hg = H // G
         W = Hg * 128
         rows = S_local * B
-        S_all = S_local * self.world
-        out = torch.empty((rows, H * 128), dtype=q.dtype, device=q.device)
         works = []
         for g in range(G):
             ks = be["pack"](k[:, g * W:(g + 1) * W])
@@ -180,9 +180,18 @@ class ContextParallelAttention:
             wk = dist.all_gather_into_tensor(kf, ks, group=self.group, async_op=True)
             wv = dist.all_gather_into_tensor(vf, vs, group=self.group, async_op=True)
             works.append((wk, wv, kf, vf, ks, vs))
-        for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
+        return dict(works=works, S_local=S_local, B=B, H=H, Hg=Hg, W=W, rows=rows, be=be)
+
+    def finish(self, q: torch.Tensor, pending: dict) -> torch.Tensor:
+        be, W, Hg, B, S_local = pending["be"], pending["W"], pending["Hg"], pending["B"], pending["S_local"]
+        S_all = S_local * self.world
+        out = torch.empty((pending["rows"], pending["H"] * 128), dtype=q.dtype, device=q.device)
+        for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(pending["works"]):
             wk.wait()
             wv.wait()
             vt = be["transpose_v"](vf, S_all, B, Hg)
             be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
         return out
+
+    def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int) -> torch.Tensor:
+        return self.finish(q, self.start(k, v, S_local, B, H))
