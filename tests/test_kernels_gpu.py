@@ -22,13 +22,38 @@ def _rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
+def test_gemm_pingpong_bitwise_equals_classic_and_is_race_free():
+    """The ping-pong kernels accumulate every output element over K in the same order as the one-barrier-per-tile kernel, so
+    the three must agree BITWISE; repeated launches must reproduce themselves (a staging race - an LDS half-tile read before
+    its DMA landed or restaged before its last read - shows up as a run-to-run or kernel-to-kernel difference)."""
+    from gen3c_amd import ops
+    dev = _dev()
+    for (M, N, K, epi) in [(7040, 4096, 4096, 2), (2048, 12288, 4096, 0), (1000, 1024, 16384, 1), (513, 264, 192, 0), (256, 256, 64, 3)]:
+        g = torch.Generator(device=dev).manual_seed(M + N + K)
+        a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        gate = torch.randn(1, N, device=dev, generator=g).to(torch.bfloat16)
+        res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+        kw = dict(gate=gate, residual=res) if epi == 2 else (dict(gate=gate) if epi == 3 else {})
+        outs = {}
+        for variant in (0, 1, 2):
+            ops.set_option("gemm_pingpong", variant)
+            first = ops.gemm_nt(a, w, epilogue=epi, **kw).clone()
+            for _ in range(8):
+                again = ops.gemm_nt(a, w, epilogue=epi, **kw)
+                assert torch.equal(first, again), f"variant {variant} not reproducible at {M}x{N}x{K}"
+            outs[variant] = first
+        ops.set_option("gemm_pingpong", 2)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"ping-pong != classic at {M}x{N}x{K} epi {epi}"
+
+
 def _report(name, got, ref):
     err = (got.float() - ref.float()).abs()
     print(f"[{name}] rel_l2={_rel_l2(got, ref):.3e} max_abs={float(err.max()):.3e} ref_absmax={float(ref.abs().max()):.3e}")
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 260, 136), (1000, 64, 328), (56, 1024, 4096),
-                                   (2048, 4096, 1024)])
+                                   (2048, 4096, 1024), (300, 520, 128), (257, 264, 192), (640, 256, 320)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("regstage", [0, 1, 2, 3, 4])
 def test_gemm_nt(M, N, K, epi, regstage):
