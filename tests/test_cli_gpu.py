@@ -90,3 +90,55 @@ def test_gen3c_single_image_cli_autoregressive_tiny(tmp_path):
         "--num_video_frames", "17", "--trajectory", "left"])
     video = cli.demo(args)
     assert video.shape == (17, H, W, 3) and video.dtype == np.uint8
+
+
+def _scene(H, W, F, seed=0):
+    rng = np.random.RandomState(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    imgs = np.stack([np.stack([np.sin(xs / (7 + f)), np.cos(ys / (5 + f)), np.sin((xs + ys) / 11)]) for f in range(F)]).astype(np.float32)
+    depth = np.stack([(2.0 + 0.01 * xs + 0.02 * f)[None] for f in range(F)]).astype(np.float32)
+    mask = (rng.rand(F, 1, H, W) < 0.9).astype(np.float32)
+    K = np.repeat(np.array([[80, 0, W / 2], [0, 80, H / 2], [0, 0, 1]], np.float32)[None], F, 0)
+    w2c = np.repeat(np.eye(4, dtype=np.float32)[None], F, 0)
+    w2c[:, 0, 3] = -0.02 * np.arange(F)
+    return imgs, depth, mask, K, w2c
+
+
+def test_gen3c_multiview_cli_tiny_with_save_buffer(tmp_path):
+    """gen3c_multiview.py:180-268: NPZ key frames -> Cache3D_BufferSelector (top-2 buffers per target frame) -> 2 chunks."""
+    from gen3c_amd import gen3c_multiview as cli
+    H, W, N, T = 64, 96, 3, 17
+    imgs, depth, mask, K, w2c = _scene(H, W, N)
+    w2cs_all = np.repeat(np.eye(4, dtype=np.float32)[None], T, 0)
+    w2cs_all[:, 0, 3] = -0.004 * np.arange(T)
+    np.savez(tmp_path / "mv.npz", images_key_frames=imgs, depth_key_frames=depth, mask_key_frames=mask, K_key_frames=K, w2cs_key_frames=w2c,
+             w2cs_all=w2cs_all)
+    args = cli.create_parser().parse_args(["--npz_path", str(tmp_path / "mv.npz"), "--height", str(H), "--width", str(W), "--num_steps", "2",
+                                           "--random_init", "--tiny", "--num_video_frames", str(T), "--save_buffer",
+                                           "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "mv"])
+    video = cli.demo(args)
+    assert video.shape == (T, H, 3 * W, 3) and video.dtype == np.uint8  # 2 selected buffers + the generated frame, side by side
+    assert np.array_equal(np.load(tmp_path / "out" / "mv.npz")["video"], video)
+
+
+@pytest.mark.parametrize("fmt", ["pt", "dir"])
+def test_gen3c_dynamic_cli_tiny(tmp_path, fmt):
+    """gen3c_dynamic.py:190-320 + data_loader_utils.py:137-193: per-frame RGB-D sources (Cache4D), both input formats."""
+    from gen3c_amd import gen3c_dynamic as cli
+    H, W, F = 64, 96, 17
+    imgs, depth, mask, K, w2c = _scene(H, W, F, seed=1)
+    if fmt == "pt":
+        src = tmp_path / "dyn.pt"
+        torch.save(tuple(torch.from_numpy(a) for a in (imgs, depth, mask, w2c, K)), src)
+    else:
+        src = tmp_path / "dyn"
+        src.mkdir()
+        np.savez(src / "rgb.npz", rgb=np.clip((imgs.transpose(0, 2, 3, 1) + 1) * 127.5, 0, 255).astype(np.uint8))
+        np.savez(src / "depth.npz", depth=depth[:, 0])
+        np.savez(src / "mask.npz", mask=mask[:, 0])
+        np.savez(src / "camera.npz", w2c=w2c, intrinsics=K)
+    args = cli.create_parser().parse_args(["--input_image_path", str(src), "--height", str(H), "--width", str(W), "--num_steps", "2", "--random_init",
+                                           "--tiny", "--num_video_frames", str(F), "--trajectory", "right",
+                                           "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "dyn"])
+    video = cli.demo(args)
+    assert video.shape == (F, H, W, 3) and video.dtype == np.uint8
