@@ -112,9 +112,9 @@ class Session:
             video = np.concatenate([video, video_new[1:]], axis=0)
         return video
 
-    def finalize(self, video: np.ndarray) -> np.ndarray:
+    def finalize(self, video: np.ndarray, save_buffer: Optional[bool] = None) -> np.ndarray:
         """--save_buffer stacking (gen3c_single_image.py:421-460): buffers side by side, left of the generated frame."""
-        if self.args.save_buffer and self.rendered_warps:
+        if (self.args.save_buffer if save_buffer is None else save_buffer) and self.rendered_warps:
             sq = [t.squeeze(0) for t in self.rendered_warps]  # (T_chunk, n_i, C, H, W)
             n_max = max(t.shape[1] for t in sq)
             sq = [torch.nn.functional.pad(t, (0, 0, 0, 0, 0, 0, 0, n_max - t.shape[1]), value=-1.0) for t in sq]

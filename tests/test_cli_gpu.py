@@ -142,3 +142,32 @@ def test_gen3c_dynamic_cli_tiny(tmp_path, fmt):
                                            "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "dyn"])
     video = cli.demo(args)
     assert video.shape == (F, H, W, 3) and video.dtype == np.uint8
+
+
+def test_persistent_model_seed_and_two_requests(tmp_path):
+    """gen3c_persistent.py:55-569: models built once; single-image seeding -> 2-chunk autoregressive request with estimated depths
+    returned; then multi-frame (Cache4D) seeding on the same object."""
+    from gen3c_amd import gen3c_persistent as gp
+    H, W = 64, 96
+    args = gp.create_parser().parse_args(["--height", str(H), "--width", str(W), "--num_steps", "2", "--random_init", "--tiny",
+                                          "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "req"])
+    model = gp.Gen3cPersistentModel(args)
+    imgs, depth, mask, K, w2c = _scene(H, W, 9, seed=2)
+    img01 = ((imgs + 1) / 2).transpose(0, 2, 3, 1)
+    fl = np.stack([K[:, 0, 0], K[:, 1, 1]], 1)
+    pp = np.stack([K[:, 0, 2] / W, K[:, 1, 2] / H], 1)
+    res = np.tile([[W, H]], (9, 1))
+    out = model.seed_model_from_values(img01[:1], depth[:1, 0], w2c[:1], fl[:1], pp[:1], res[:1])
+    assert out[3].tolist() == [[W, H]] and model.seeding_image.shape == (1, 3, 1, H, W)
+    T = 17
+    cams = np.repeat(np.eye(4, dtype=np.float32)[None], T, 0)
+    cams[:, 0, 3] = -0.003 * np.arange(T)
+    r = model.inference_on_cameras(cams, np.repeat(K[:1], T, 0), fps=24, return_estimated_depths=True)
+    assert r["video"].shape == (1, T, 3, H, W) and r["predicted_depth"].shape == (T, 1, H, W)
+    assert np.isfinite(r["predicted_depth"][8]).all() and np.isnan(r["predicted_depth"][3]).all()
+    assert model.cache.input_image.shape[2] == 2  # the AR step pushed the last frame into the buffer
+    model.clear_cache()
+    model.seed_model_from_values(img01, depth[:, 0], w2c, fl, pp, res, masks_np=mask[:, 0])
+    r = model.inference_on_cameras(cams[:9], np.repeat(K[:1], 9, 0), fps=12, save_buffer=True)
+    assert r["video"].shape == (1, 9, 3, H, W) and model.pipeline.fps == 12
+    assert np.load(r["video_save_path"])["video"].shape == (9, H, 2 * W, 3)
