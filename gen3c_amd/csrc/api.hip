@@ -31,6 +31,7 @@ int g3_opt_gemm_regstage = env_int("G3_GEMM_REGSTAGE", 0);
 int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 3);
 int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 int g3_opt_gemm_wide_store = env_int("G3_GEMM_WIDE_STORE", 1);
+int g3_opt_splat_tiled = env_int("G3_SPLAT_TILED", 1);
 int g3_opt_gemm_pingpong = env_int("G3_GEMM_PINGPONG", 2);
 int g3_opt_gemm_unpinned = env_int("G3_GEMM_UNPINNED", 1);  // measured: pinning the LDS prefetch does not help this kernel (profiles/r1_v4_gemm_pin_ab.txt)
 
@@ -38,6 +39,7 @@ extern "C" int g3_set_option(const char* name, int value) {
     if (!name) return g3_set_error(G3_ERR_ARG, "g3_set_option: null name");
     if (!strcmp(name, "gemm_regstage")) { g3_opt_gemm_regstage = value; return G3_OK; }
     if (!strcmp(name, "gemm_wide_store")) { g3_opt_gemm_wide_store = value; return G3_OK; }
+    if (!strcmp(name, "splat_tiled")) { g3_opt_splat_tiled = value; return G3_OK; }
     if (!strcmp(name, "gemm_pingpong")) { g3_opt_gemm_pingpong = value; return G3_OK; }
     if (!strcmp(name, "gemm_unpinned")) { g3_opt_gemm_unpinned = value; return G3_OK; }
     if (!strcmp(name, "gemm_rowmajor_tiles")) { g3_opt_gemm_rowmajor_tiles = value; return G3_OK; }

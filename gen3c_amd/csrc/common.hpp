@@ -30,6 +30,7 @@ extern int g3_opt_gemm_rowmajor_tiles;  // 1: plain row-major tile order inside 
 extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop (no sched_group_barrier pinning) (A/B)
 extern int g3_opt_gemm_pingpong;        // plain K%64==0 GEMMs: 2 (default) / 1 = phase-staggered ping-pong kernel with 2 / 4 phases per K tile, 0 = classic
 extern int g3_opt_gemm_wide_store;      // 1 (default): LDS-transposed full-line epilogue when the operands allow 16-byte rows
+extern int g3_opt_splat_tiled;          // 1 (default): LDS-windowed splat; 0: direct global atomics (A/B)
 extern int g3_opt_attn_variant;   // 1: non-pipelined attention kernel, 2: software-pipelined (default)
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }

@@ -134,6 +134,109 @@ __global__ __launch_bounds__(256) void warp_splat_kernel(const float* __restrict
     }
 }
 
+// Tiled splat (default): the accumulator atomics of the kernel above are bound by the L2's read-modify-write rate (20 per
+// source pixel, ~4 pixels hitting every texel channel). Here a workgroup owns a 32 x 32 tile of SOURCE pixels, whose
+// destinations are (for a smooth flow) a compact patch: it accumulates them with LDS atomics into a WIN x WIN x 5 window
+// anchored at the tile's smallest destination corner, then adds the window into the global accumulator with ONE atomic per
+// touched texel channel. Corners outside the window (depth discontinuities inside the tile, extreme zoom) go straight to
+// global atomics, so any flow stays correct. Same contributions as the direct kernel; only the (already order-dependent)
+// summation order differs.
+constexpr int TS = 32;    // source tile edge
+constexpr int WIN = 48;   // destination window edge (46 KiB of LDS)
+__global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
+                                                               const float* __restrict__ flow, const float* __restrict__ maskz,
+                                                               const unsigned* __restrict__ group_max, float* __restrict__ accum,
+                                                               int n, int h, int w, int group_size, int tiles_x) {
+    __shared__ float win[WIN * WIN * ACC_C];
+    __shared__ int org[2];
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const float lmax = __uint_as_float(group_max[item / group_size]);
+    const int aw = w + 2;
+    float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
+    const int ty0 = (blockIdx.x / tiles_x) * TS, tx0 = (blockIdx.x % tiles_x) * TS;
+    if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
+    for (int i = threadIdx.x; i < WIN * WIN * ACC_C; i += 256) win[i] = 0.f;
+    __syncthreads();
+
+    // 4 pixels per thread: rows ty0 + (threadIdx.x >> 5) + 8 k, column tx0 + (threadIdx.x & 31)
+    SplatGeom g[4];
+    float wscale[4], col[4][4];  // m / dw ; r, g, b, z
+    bool on[4];
+    int mnx = 0x7fffffff, mny = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
+        on[k] = false;
+        if (py >= h || px >= w) continue;
+        const int pix = py * w + px;
+        const int64_t o = (int64_t)item * hw + pix;
+        const float m = maskz[o];
+        if (m == 0.f) continue;
+        on[k] = true;
+        const float z = zbuf[o];
+        g[k] = splat_geom(flow[((int64_t)item * 2 + 0) * hw + pix], flow[((int64_t)item * 2 + 1) * hw + pix], px, py, h, w);
+        const float logd = log1pf(fmaxf(z, 0.f));
+        const float expo = logd / (lmax + 1e-7f) * 50.0f;
+        const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
+        wscale[k] = dw;
+        col[k][0] = image[((int64_t)item * 3 + 0) * hw + pix];
+        col[k][1] = image[((int64_t)item * 3 + 1) * hw + pix];
+        col[k][2] = image[((int64_t)item * 3 + 2) * hw + pix];
+        col[k][3] = z;
+        mnx = min(mnx, g[k].fx);
+        mny = min(mny, g[k].fy);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, o, 64));
+        mny = min(mny, __shfl_xor(mny, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&org[0], mnx); atomicMin(&org[1], mny); }
+    __syncthreads();
+    const int ox = org[0], oy = org[1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!on[k]) continue;
+        const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
+        const float m = maskz[(int64_t)item * hw + py * w + px];
+        const float dw = wscale[k];
+        const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
+        const int ys[4] = {g[k].fy, g[k].cy, g[k].fy, g[k].cy};
+        const int xs[4] = {g[k].fx, g[k].fx, g[k].cx, g[k].cx};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float wt = wts[c];
+            const int lx = xs[c] - ox, ly = ys[c] - oy;
+            const float v[ACC_C] = {col[k][0] * wt, col[k][1] * wt, col[k][2] * wt, col[k][3] * wt, wt};
+            if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
+                float* a = win + (ly * WIN + lx) * ACC_C;
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) atomicAdd(a + e, v[e]);
+            } else {
+                float* a = acc_item + ((int64_t)ys[c] * aw + xs[c]) * ACC_C;
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) unsafeAtomicAdd(a + e, v[e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (ox == 0x7fffffff) return;  // nothing valid in this tile
+    for (int i = threadIdx.x; i < WIN * WIN; i += 256) {
+        const float* a = win + i * ACC_C;
+        // a texel is touched iff some contribution was added; contributions may be exact zeros (zero bilinear weight), which
+        // the direct kernel also adds - skipping them changes nothing
+        if (a[0] == 0.f && a[1] == 0.f && a[2] == 0.f && a[3] == 0.f && a[4] == 0.f) continue;
+        const int ly = i / WIN, lx = i - ly * WIN;
+        const int gy = oy + ly, gx = ox + lx;
+        if (gy > h + 1 || gx > w + 1) continue;  // cannot happen (corners are clamped), defensive
+        float* d = acc_item + ((int64_t)gy * aw + gx) * ACC_C;
+#pragma unroll
+        for (int e = 0; e < ACC_C; ++e)
+            if (a[e] != 0.f) unsafeAtomicAdd(d + e, a[e]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // (3) resolve
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,8 +474,14 @@ extern "C" int g3_warp_splat_f32(const float* image, const float* z, const float
                                  const void* group_max, float* accum, int n, int h, int w, int group_size, void* stream) {
     if (!image || !z || !flow || !maskz || !group_max || !accum) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_f32: null operand");
     if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_f32: bad shape");
-    hipLaunchKernelGGL(warp_splat_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, image, z, flow, maskz,
-                       (const unsigned*)group_max, accum, n, h, w, group_size);
+    if (g3_opt_splat_tiled) {
+        const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS;
+        hipLaunchKernelGGL(warp_splat_tiled_kernel, dim3(tiles_x * tiles_y, n), dim3(256), 0, (hipStream_t)stream, image, z, flow, maskz,
+                           (const unsigned*)group_max, accum, n, h, w, group_size, tiles_x);
+    } else {
+        hipLaunchKernelGGL(warp_splat_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, image, z, flow, maskz,
+                           (const unsigned*)group_max, accum, n, h, w, group_size);
+    }
     return g3_check_launch("g3_warp_splat_f32");
 }
 

@@ -31,7 +31,8 @@ def main():
     w2cs = torch.eye(4, device=dev).repeat(1, F, 1, 1)
     w2cs[0, :, 0, 3] = torch.linspace(0, 0.3, F, device=dev)  # "left" trajectory, movement_distance 0.3
     Ks = t(K)[None, None].expand(1, F, 3, 3).contiguous()
-    for fg in (False, True):
+    for fg, tiled in ((False, 0), (False, 1), (True, 0), (True, 1)):
+        ops.set_option("splat_tiled", tiled)
         cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None],
                                         input_w2c=torch.eye(4, device=dev)[None], input_intrinsics=t(K)[None],
                                         filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
@@ -46,9 +47,10 @@ def main():
         ms = tm.elapsed_ms() / reps
         per_item = ms / F
         gbs = 43.2e6 / (per_item * 1e-3) / 1e9
-        print(f"render 704x1280 foreground_masking={fg}: {per_item:.3f} ms/item ({F} items, {ms:.1f} ms)  algorithmic {gbs:.0f} GB/s "
+        print(f"render 704x1280 foreground_masking={fg} splat_tiled={tiled}: {per_item:.3f} ms/item ({F} items, {ms:.1f} ms)  algorithmic {gbs:.0f} GB/s "
               f"({gbs/8000*100:.1f}% of 8 TB/s); mask coverage {float(msk.mean()):.3f}", flush=True)
 
 
 if __name__ == "__main__":
     main()
+    ops.set_option("splat_tiled", 1)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# rocprofv3 kernel-trace summary of an arbitrary command: tools/gpu_prof.sh <name> <cmd...>  -> gpurun_out/<name>_kernel_stats.csv
+name=$1; shift
+mkdir -p gpurun_out; ROOTD=$(pwd); export TMPDIR=/tmp PYTHONUNBUFFERED=1
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof_$name -o $name -- "$@" > $ROOTD/gpurun_out/prof_$name.log 2>&1
+echo "rc=$? rocprof"; cd $ROOTD
+db=$(find gpurun_out/prof_$name -name "*.db" | head -1)
+python tools/rocpd_summary.py $db gpurun_out/${name}_kernel_stats.csv
