@@ -37,6 +37,9 @@ SIGNATURES = {
     "g3_warp_resolve_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "g3_mesh_occlusion_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "g3_unproject_points_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "g3_dit_patchify_bf16": [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
+    "g3_dit_unpatchify_bf16": [vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "g3_timestep_embedding_bf16": [vp, vp, vp, vp, i32, i32, vp],
     "g3_reliable_depth_mask_f32": [vp, vp, i32, i32, i32, i32, f32, f32, vp],
     "g3_align_depth_workspace_bytes": [i32, i32],
     "g3_align_depth_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, C.c_size_t, i32, i32, vp],

@@ -339,6 +339,7 @@ class VideoExtendGeneralDIT(nn.Module):
             raise NotImplementedError("Scalar feature is not implemented yet.")  # same as the reference
         B, C, T, H, W = x.shape
         dev = x.device
+        sources = [(x.to(torch.bfloat16).contiguous(), True)]
         if _is_video(data_type):
             assert condition_video_input_mask is not None, "condition_video_input_mask is required for video data type"
             if self.cp_group is not None:
@@ -347,23 +348,22 @@ class VideoExtendGeneralDIT(nn.Module):
                     condition_video_indicator = split_inputs_cp(condition_video_indicator, 2, self.cp_group)
                 if condition_video_pose is not None:
                     condition_video_pose = split_inputs_cp(condition_video_pose, 2, self.cp_group)
-            parts = [x, condition_video_input_mask.to(x.dtype)]
+            sources.append((condition_video_input_mask.to(torch.bfloat16).contiguous(), True))
             if condition_video_pose is not None:
-                parts.append(condition_video_pose.to(x.dtype))
-            x = torch.cat(parts, dim=1)
+                sources.append((condition_video_pose.to(torch.bfloat16).contiguous(), True))
         if self.concat_padding_mask:
-            pm = _nearest_resize(padding_mask, (H, W)).to(x.dtype)  # torchvision NEAREST resize (general_dit.py:305-307)
-            x = torch.cat([x, pm[:, None, None, :, :].expand(B, 1, T, H, W)], dim=1)
-        assert x.shape[1] * self.patch_spatial ** 2 * self.patch_temporal == self.patch_dim, \
-            f"channel mismatch: got {x.shape[1]} input channels"
+            pm = _nearest_resize(padding_mask, (H, W)).to(torch.bfloat16)  # torchvision NEAREST resize (general_dit.py:305-307)
+            sources.append((pm.reshape(B, 1, H, W).contiguous(), False))  # broadcast over T by the gather kernel
+        c_in = sum(t.shape[1] for t, _ in sources)
+        assert c_in * self.patch_spatial ** 2 * self.patch_temporal == self.patch_dim, f"channel mismatch: got {c_in} input channels"
 
         ps, pt = self.patch_spatial, self.patch_temporal
         Tp, Hp, Wp = T // pt, H // ps, W // ps
         S = Tp * Hp * Wp
         D = self.model_channels
-        # patch gather "b c (t r) (h m) (w n) -> (t h w) b (c r m n)"  (blocks.py:154-159 + THWBD order)
-        patches = (x.view(B, -1, Tp, pt, Hp, ps, Wp, ps).permute(2, 4, 6, 0, 1, 3, 5, 7)
-                   .reshape(S * B, self.patch_dim).contiguous())
+        # channel concat (general_dit_video_conditioned.py:77-101) + patch gather "b c (t r) (h m) (w n) -> (t h w) b (c r m n)"
+        # (blocks.py:154-159 + THWBD order) in one HIP kernel
+        patches = ops.dit_patchify(sources, B, T, H, W, pt, ps)
 
         pk = self._pack()
         P = pk["P"]
@@ -372,18 +372,12 @@ class VideoExtendGeneralDIT(nn.Module):
         xs = ops.gemm_nt(patches, P["x_embedder.proj.1.weight"])  # [S*B, D]
 
         # ---- timestep embedding (blocks.py:38-80) + affine RMSNorm (general_dit.py:173-177)
-        ts = timesteps.flatten()
-        half = D // 2
-        expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / (half - 0.0)
-        ang = ts[:, None].float() * torch.exp(expo)[None, :]
-        t_sin = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(ts.dtype if ts.dtype.is_floating_point else torch.bfloat16)
-        t_sin = t_sin.to(torch.bfloat16).contiguous()  # [B, D]
-        if t_sin.shape[0] != B:
-            t_sin = t_sin.expand(B, -1).contiguous()
+        ts = timesteps.flatten().to(torch.float32)
+        if ts.shape[0] != B:
+            ts = ts.expand(B)
+        t_sin, emb = ops.timestep_embedding(ts.contiguous(), P["affline_norm.weight"], D)
         h1 = ops.gemv(t_sin, P["t_embedder.1.linear_1.weight"])
         adaln_lora = ops.gemv(h1, P["t_embedder.1.linear_2.weight"], act_in=1)  # [B, 3D]
-        tf = t_sin.float()
-        emb = (tf * torch.rsqrt(tf.pow(2).mean(-1, keepdim=True) + 1e-6) * P["affline_norm.weight"].float()).to(torch.bfloat16)
 
         # ---- context
         M = crossattn_emb.shape[1]
@@ -432,10 +426,7 @@ class VideoExtendGeneralDIT(nn.Module):
         shift, scale = self._modulation(emb, fl, adaln_lora[:, : 2 * D], 2)
         h = ops.layernorm_modulate(xs, shift, scale)
         y = ops.gemm_nt(h, P["final_layer.linear.weight"])  # [S*B, p1*p2*t*C]
-        Co = self.out_channels
-        y = (y.view(Tp, Hp, Wp, B, ps, ps, pt, Co).permute(3, 7, 0, 6, 1, 4, 2, 5)
-             .reshape(B, Co, Tp * pt, Hp * ps, Wp * ps))
-        return y.contiguous()
+        return ops.dit_unpatchify(y, B, self.out_channels, T, H, W, pt, ps)
 
     def _modulation(self, emb, ada, lora, n):
         """(shift, scale[, gate]) = chunk_n( W2 . (W1 . SiLU(emb)) + adaln_lora )   (blocks.py:442-447)"""

@@ -182,6 +182,49 @@ def add_inplace(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def dit_patchify(sources, B: int, T: int, H: int, W: int, patch_t: int, patch_s: int) -> torch.Tensor:
+    """sources: list of (tensor, has_t) - bf16 contiguous [B,C_i,T,H,W] (has_t) or [B,C_i,H,W] broadcast over T.
+    -> patches [(T/pt)*(H/ps)*(W/ps)*B, sum(C_i)*pt*ps*ps] bf16, rows (t h w b), columns (c r m n). See g3_dit_patchify_bf16."""
+    import ctypes as C
+    assert 1 <= len(sources) <= 4
+    ptrs, chans, has_t = [], [], []
+    for i, (t, ht) in enumerate(sources):
+        assert t.is_contiguous() and t.shape[0] == B and tuple(t.shape[-2:]) == (H, W) and (t.dim() == 5 and t.shape[2] == T if ht else t.dim() == 4)
+        ptrs.append(_dev(t, f"source{i}"))
+        chans.append(int(t.shape[1]))
+        has_t.append(1 if ht else 0)
+    n = len(sources)
+    ctot = sum(chans)
+    out = torch.empty(((T // patch_t) * (H // patch_s) * (W // patch_s) * B, ctot * patch_t * patch_s * patch_s), dtype=torch.bfloat16,
+                      device=sources[0][0].device)
+    lib = _lib.load()
+    _lib.check(lib.g3_dit_patchify_bf16((C.c_void_p * n)(*ptrs), (C.c_int * n)(*chans), (C.c_int * n)(*has_t), n, out.data_ptr(), B, T, H, W,
+                                        patch_t, patch_s, _stream()), "g3_dit_patchify_bf16")
+    return out
+
+
+def dit_unpatchify(y: torch.Tensor, B: int, C_out: int, T: int, H: int, W: int, patch_t: int, patch_s: int) -> torch.Tensor:
+    """y [(T/pt)(H/ps)(W/ps) B, ps*ps*pt*C_out] -> [B, C_out, T, H, W]. See g3_dit_unpatchify_bf16."""
+    rows, cols, ldy = _rowmajor2d(y, "y")
+    assert rows == (T // patch_t) * (H // patch_s) * (W // patch_s) * B and cols == patch_s * patch_s * patch_t * C_out
+    out = torch.empty((B, C_out, T, H, W), dtype=torch.bfloat16, device=y.device)
+    lib = _lib.load()
+    _lib.check(lib.g3_dit_unpatchify_bf16(_dev(y, "y"), ldy, out.data_ptr(), B, C_out, T, H, W, patch_t, patch_s, _stream()), "g3_dit_unpatchify_bf16")
+    return out
+
+
+def timestep_embedding(timesteps: torch.Tensor, norm_weight: torch.Tensor, D: int):
+    """timesteps f32 [B] -> (t_sin bf16 [B,D], emb bf16 [B,D]). See g3_timestep_embedding_bf16."""
+    assert timesteps.dim() == 1 and timesteps.is_contiguous() and norm_weight.numel() == D
+    Bn = timesteps.shape[0]
+    t_sin = torch.empty((Bn, D), dtype=torch.bfloat16, device=timesteps.device)
+    emb = torch.empty_like(t_sin)
+    lib = _lib.load()
+    _lib.check(lib.g3_timestep_embedding_bf16(_dev(timesteps, "timesteps", torch.float32), _dev(norm_weight, "norm_weight"), t_sin.data_ptr(),
+                                              emb.data_ptr(), Bn, D, _stream()), "g3_timestep_embedding_bf16")
+    return t_sin, emb
+
+
 def edm_prepare_input(xt, gt_latent, noise, indicator, T: int, hw: int, augment_sigma: float, c_in_aug: float,
                       c_in_bf16: float, c_in_step: float):
     """-> (new_xt, new_xt_scaled), both bf16 like xt. See g3_edm_prepare_input_bf16."""

@@ -91,6 +91,18 @@ int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, c
 /* x += y (n % 8 == 0): "x = x + extra_per_block_pos_emb" (blocks.py:547-548). */
 int g3_add_inplace_bf16(void* x, const void* y, int64_t n, void* stream);
 
+/* DiT input/output plumbing. patchify: channel-concatenates up to 4 bf16 sources ([B,C_i,T,H,W] contiguous, or [B,C_i,H,W]
+ * broadcast over T when has_t[i] == 0 - the padding mask) and gathers patch_t x patch_s x patch_s patches into the token-major
+ * matrix out[(t h w) b][(c r m n)] the embedding GEMM reads (general_dit_video_conditioned.py:77-101, blocks.py:154-159).
+ * srcs / chans / has_t are HOST arrays of n_src entries. unpatchify: final-layer rows y[(t h w) b][(p1 p2 t C)] (ld = ldy) ->
+ * out [B,C_out,T,H,W] (general_dit.py:348-357). timestep_embedding: timesteps f32 [B] (device) -> t_sin bf16 [B,D] = [cos | sin]
+ * sinusoid (blocks.py:38-57) and emb bf16 [B,D] = its affine RMSNorm with norm_weight [D], eps 1e-6 (general_dit.py:173-177). */
+int g3_dit_patchify_bf16(const void* const* srcs, const int* chans, const int* has_t, int n_src, void* out, int B, int T, int H,
+                         int W, int patch_t, int patch_s, void* stream);
+int g3_dit_unpatchify_bf16(const void* y, int64_t ldy, void* out, int B, int C_out, int T, int H, int W, int patch_t, int patch_s,
+                           void* stream);
+int g3_timestep_embedding_bf16(const float* timesteps, const void* norm_weight, void* t_sin, void* emb, int B, int D, void* stream);
+
 /* ---- EDM-Euler sampler step (model_v2w.py:130-149, 201-259; diffusers 0.32.2 EDMEulerScheduler) ------------------
  * Two fused elementwise passes around the two network calls of one denoise step, over a [B,C,T,H,W] latent of n
  * elements (hw = H*W, indicator = f32 [T], 1 on conditioning frames). Scalar coefficients are evaluated by the host
