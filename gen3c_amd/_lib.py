@@ -25,6 +25,8 @@ SIGNATURES = {
     "g3_event_elapsed_ms": [vp, vp, C.POINTER(f32)],
     "g3_event_destroy": [vp],
     "g3_gemm_bf16_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, i64, vp, i64, vp],
+    "g3_flash_attn_fwd_kvseg_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i64, vp, i64, i64, i64, i32, i32, i32,
+                                     i32, i32, f32, vp],
     "g3_gemv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "g3_flash_attn_fwd_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32,
                                i32, i32, f32, vp],

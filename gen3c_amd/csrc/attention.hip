@@ -42,6 +42,8 @@ struct AttnParams {
     bf16_t* O; int64_t o_row, o_batch, o_head;
     int Sq, Skv;
     float scale_log2;  // softmax_scale * log2(e)
+    int vt_seg_len;        // > 0: V^T is stored in key segments of this many keys (multiple of 64), segment s at Vt + s*vt_seg_stride
+    int64_t vt_seg_stride;  // elements between segments (context parallel: rank-major all-gather of per-rank V^T shards)
 };
 
 G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
@@ -525,11 +527,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kbytes + o1),
                                          (__attribute__((address_space(3))) void*)(d + 512 * 8), 16, 0, 0);
     };
+    const uint32_t seg_len = (uint32_t)p.vt_seg_len, seg_bytes = (uint32_t)p.vt_seg_stride * 2u;
     auto dma_v = [&](int kv0, int slot) {
         bf16_t* d = sV + slot * HD * KVB + wave * 64 * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane0 + (uint32_t)kv0 * 2u),
+        uint32_t tile_off = (uint32_t)kv0 * 2u;
+        if (seg_len) {  // a 64-key tile never straddles segments (seg_len % 64 == 0)
+            const uint32_t sg = (uint32_t)kv0 / seg_len;
+            tile_off = sg * seg_bytes + ((uint32_t)kv0 - sg * seg_len) * 2u;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane0 + tile_off),
                                          (__attribute__((address_space(3))) void*)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane1 + (uint32_t)kv0 * 2u),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane1 + tile_off),
                                          (__attribute__((address_space(3))) void*)(d + 512 * 8), 16, 0, 0);
     };
 
@@ -722,11 +730,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
 }  // namespace
 
-extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k,
-                                      int64_t k_row, int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row,
-                                      int64_t vt_batch, int64_t vt_head, void* o, int64_t o_row, int64_t o_batch,
-                                      int64_t o_head, int Sq, int Skv, int B, int H, int head_dim, float softmax_scale,
-                                      void* stream) {
+static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
+                             int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
+                             int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H,
+                             int head_dim, float softmax_scale, void* stream) {
     if (!q || !k || !vt || !o) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
     if (head_dim != HD) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: head_dim %d unsupported (128 only)", head_dim);
     if (Sq <= 0 || Skv <= 0 || B <= 0 || H <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: bad shape");
@@ -735,7 +742,10 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: strides must keep 16-byte (q,k,vt) / 8-byte (o) alignment");
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) || ((uintptr_t)o & 7))
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: misaligned pointer");
-    if (vt_row < ((Skv + 7) & ~7)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: vt leading dim %lld < S_kv rounded to 8", (long long)vt_row);
+    const int kv_span = vt_seg_len > 0 ? vt_seg_len : Skv;  // keys addressed through one vt_row
+    if (vt_seg_len < 0 || (vt_seg_len > 0 && ((vt_seg_len % KVB) || (Skv % vt_seg_len) || (vt_seg_stride & 7) || vt_seg_stride <= 0)))
+        return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segments must be a multiple of 64 keys, tile S_kv exactly, 16-byte aligned stride");
+    if (vt_row < ((kv_span + 7) & ~7)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: vt leading dim %lld < keys per row rounded to 8", (long long)vt_row);
     AttnParams p;
     p.Q = (const bf16_t*)q; p.q_row = q_row; p.q_batch = q_batch; p.q_head = q_head;
     p.K = (const bf16_t*)k; p.k_row = k_row; p.k_batch = k_batch; p.k_head = k_head;
@@ -743,10 +753,13 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     p.O = (bf16_t*)o; p.o_row = o_row; p.o_batch = o_batch; p.o_head = o_head;
     p.Sq = Sq; p.Skv = Skv;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
     int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined (both kept for A/B), 3 LDS-DMA + pinned interleave (default)
-    if (variant >= 3 && vt_row < ((Skv + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
+    if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
+    if (vt_seg_len > 0 && variant != 3)
+        return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
     if (!attr_set) {
         const void* fns[6] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
@@ -767,4 +780,22 @@ extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_ba
     else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8>), (flash_attn_fwd_v3_kernel<1, 6, 8>));
 #undef G3_LAUNCH_ATTN
     return g3_check_launch("g3_flash_attn_fwd_bf16");
+}
+
+extern "C" int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k,
+                                      int64_t k_row, int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row,
+                                      int64_t vt_batch, int64_t vt_head, void* o, int64_t o_row, int64_t o_batch,
+                                      int64_t o_head, int Sq, int Skv, int B, int H, int head_dim, float softmax_scale,
+                                      void* stream) {
+    return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, 0, 0, o, o_row, o_batch, o_head,
+                             Sq, Skv, B, H, head_dim, softmax_scale, stream);
+}
+
+extern "C" int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row,
+                                            int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch,
+                                            int64_t vt_head, int vt_seg_len, int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch,
+                                            int64_t o_head, int Sq, int Skv, int B, int H, int head_dim, float softmax_scale, void* stream) {
+    if (vt_seg_len <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: vt_seg_len must be positive");
+    return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, vt_seg_len, vt_seg_stride, o, o_row,
+                             o_batch, o_head, Sq, Skv, B, H, head_dim, softmax_scale, stream);
 }

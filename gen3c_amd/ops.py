@@ -148,12 +148,14 @@ def transpose_v(v: torch.Tensor, S: int, B: int, H: int, out: Optional[torch.Ten
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv: int, B: int, H: int,
                out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None) -> torch.Tensor:
-    """q: [Sq*B, H*128], k: [Skv*B, H*128] (rows (s,b), b fastest), vt: [B, H, 128, ldvt] -> out [Sq*B, H*128]."""
+    """q: [Sq*B, H*128], k: [Skv*B, H*128] (rows (s,b), b fastest), vt: [B, H, 128, ldvt] -> out [Sq*B, H*128].
+    vt may also be 5-D [n_seg, B, H, 128, ld_seg]: V^T in key segments of Skv / n_seg keys each (a rank-major all-gather of
+    per-rank V^T shards, see g3_flash_attn_fwd_kvseg_bf16)."""
     qr, qw, ldq = _rowmajor2d(q, "q")
     kr, kw, ldk = _rowmajor2d(k, "k")
     assert qr == Sq * B and kr == Skv * B and qw == H * 128 and kw == H * 128
-    assert vt.dim() == 4 and vt.shape[:3] == (B, H, 128) and vt.is_contiguous()
-    ldvt = vt.shape[3]
+    assert vt.is_contiguous() and vt.dim() in (4, 5) and tuple(vt.shape[-4:-1]) == (B, H, 128)
+    ldvt = vt.shape[-1]
     if out is None:
         out = torch.empty((Sq * B, H * 128), dtype=torch.bfloat16, device=q.device)
     if softmax_scale is None:
@@ -163,12 +165,14 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv:
     if _KERNEL_TIMERS is not None:
         timer = HipTimer()
         timer.start()
-    _lib.check(lib.g3_flash_attn_fwd_bf16(
-        _dev(q, "q"), ldq * B, ldq, 128,
-        _dev(k, "k"), ldk * B, ldk, 128,
-        _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,
-        _dev(out, "out"), out.stride(0) * B, out.stride(0), 128,
-        Sq, Skv, B, H, 128, float(softmax_scale), _stream()), "g3_flash_attn_fwd_bf16")
+    common_q = (_dev(q, "q"), ldq * B, ldq, 128, _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt)
+    common_o = (_dev(out, "out"), out.stride(0) * B, out.stride(0), 128, Sq, Skv, B, H, 128, float(softmax_scale), _stream())
+    if vt.dim() == 5:
+        n_seg = vt.shape[0]
+        assert Skv % n_seg == 0
+        _lib.check(lib.g3_flash_attn_fwd_kvseg_bf16(*common_q, Skv // n_seg, B * H * 128 * ldvt, *common_o), "g3_flash_attn_fwd_kvseg_bf16")
+    else:
+        _lib.check(lib.g3_flash_attn_fwd_bf16(*common_q, *common_o), "g3_flash_attn_fwd_bf16")
     if timer is not None:
         timer.stop()
         _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H), timer))

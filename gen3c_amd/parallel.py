@@ -163,7 +163,11 @@ class ContextParallelAttention:
 
     def start(self, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int):
         """Issue the K / V all-gathers of every head group (async). Call as soon as K and V exist: whatever the caller
-        launches before finish() - the Q projection and its norm/RoPE in the DiT - hides part of the first group's exchange."""
+        launches before finish() - the Q projection and its norm/RoPE in the DiT - hides part of the first group's exchange.
+
+        V is transposed LOCALLY (this rank's S_local keys) and the V^T shards are gathered rank-major; the attention kernel reads
+        them as key segments, so no rank re-transposes the full-length V (needs S_local % 64 == 0, true for the 3 520-token
+        latent frames; otherwise V is gathered row-major and transposed after the exchange)."""
         be = self.backend or _default_backend()
         G = self.head_groups
         while H % G != 0:
@@ -171,16 +175,21 @@ class ContextParallelAttention:
         Hg = H // G
         W = Hg * 128
         rows = S_local * B
+        segmented = S_local % 64 == 0
         works = []
         for g in range(G):
             ks = be["pack"](k[:, g * W:(g + 1) * W])
-            vs = be["pack"](v[:, g * W:(g + 1) * W])
             kf = torch.empty((self.world * rows, W), dtype=k.dtype, device=k.device)
-            vf = torch.empty((self.world * rows, W), dtype=v.dtype, device=v.device)
             wk = dist.all_gather_into_tensor(kf, ks, group=self.group, async_op=True)
+            if segmented:
+                vs = be["transpose_v"](v[:, g * W:(g + 1) * W], S_local, B, Hg)  # [B, Hg, 128, S_local]
+                vf = torch.empty((self.world * vs.shape[0],) + tuple(vs.shape[1:]), dtype=v.dtype, device=v.device)  # dim-0 concat
+            else:
+                vs = be["pack"](v[:, g * W:(g + 1) * W])
+                vf = torch.empty((self.world * rows, W), dtype=v.dtype, device=v.device)
             wv = dist.all_gather_into_tensor(vf, vs, group=self.group, async_op=True)
             works.append((wk, wv, kf, vf, ks, vs))
-        return dict(works=works, S_local=S_local, B=B, H=H, Hg=Hg, W=W, rows=rows, be=be)
+        return dict(works=works, S_local=S_local, B=B, H=H, Hg=Hg, W=W, rows=rows, be=be, segmented=segmented)
 
     def finish(self, q: torch.Tensor, pending: dict) -> torch.Tensor:
         be, W, Hg, B, S_local = pending["be"], pending["W"], pending["Hg"], pending["B"], pending["S_local"]
@@ -189,7 +198,7 @@ class ContextParallelAttention:
         for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(pending["works"]):
             wk.wait()
             wv.wait()
-            vt = be["transpose_v"](vf, S_all, B, Hg)
+            vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
             be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
         return out
 

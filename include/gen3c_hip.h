@@ -71,6 +71,15 @@ int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_
                            int64_t vt_head, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv,
                            int B, int H, int head_dim, float softmax_scale, void* stream);
 
+/* Same, with V^T stored in KEY SEGMENTS: keys [s*vt_seg_len, (s+1)*vt_seg_len) live in the block at vt + s*vt_seg_stride (each block
+ * laid out as above with its own vt_row >= vt_seg_len). vt_seg_len must be a multiple of 64 and divide S_kv. This is what a rank-major
+ * all-gather of per-rank V^T shards produces under context parallelism (module/parallel.py:110-163 gathers; TE's CP attention is the
+ * reference counterpart), so no rank has to re-transpose the gathered V. */
+int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row,
+                                 int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head,
+                                 int vt_seg_len, int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq,
+                                 int Skv, int B, int H, int head_dim, float softmax_scale, void* stream);
+
 /* V [S][B][H][128] (row stride ld_in) -> V^T [B][H][128][ldvt], zero-filling kv in [S, ldvt). */
 int g3_transpose_v_bf16(const void* v, int64_t ld_in, void* vt, int64_t ldvt, int S, int B, int H, int head_dim,
                         void* stream);

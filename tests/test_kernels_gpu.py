@@ -193,6 +193,23 @@ def test_flash_attn_strided_views_and_zero_context_rows(attn_variant):
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
 
 
+def test_flash_attn_segmented_vt_matches_plain():
+    """g3_flash_attn_fwd_kvseg_bf16: V^T handed over as n key segments (what a rank-major all-gather of per-rank V^T shards looks
+    like) gives bit-identical output to one contiguous V^T - only the addressing of the V tiles differs."""
+    from gen3c_amd import ops
+    dev = _dev()
+    for (Sq, S_loc, n, B, H) in [(320, 128, 4, 1, 2), (200, 64, 8, 2, 3), (7040, 7040, 2, 1, 2)]:
+        Skv = S_loc * n
+        g = torch.Generator(device=dev).manual_seed(Sq + Skv)
+        q = torch.randn(Sq * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+        k = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+        v = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+        ref = ops.flash_attn(q, k, ops.transpose_v(v, Skv, B, H), Sq, Skv, B, H)
+        segs = torch.stack([ops.transpose_v(v[i * S_loc * B:(i + 1) * S_loc * B], S_loc, B, H) for i in range(n)])  # [n,B,H,128,ld]
+        out = ops.flash_attn(q, k, segs.contiguous(), Sq, Skv, B, H)
+        assert torch.equal(out, ref), (Sq, S_loc, n, B, H)
+
+
 @pytest.mark.parametrize("rows,D,B", [(64, 128, 1), (1000, 256, 2), (4096, 4096, 1), (77, 8192, 1)])
 def test_layernorm_modulate(rows, D, B):
     from gen3c_amd import ops

@@ -28,7 +28,11 @@ def _oracle_backend():
     def attention(q, k, vt, Sq, Skv, B, H, out):
         q4 = q.reshape(Sq, B, H, 128)
         k4 = k.reshape(Skv, B, H, 128)
-        v4 = vt.permute(3, 0, 1, 2)  # [S,B,H,128]
+        if vt.dim() == 5:  # rank-major V^T segments [n, B, H, 128, S_local] (context-parallel gather of local transposes)
+            n, S_loc = vt.shape[0], vt.shape[-1]
+            v4 = vt.permute(0, 4, 1, 2, 3).reshape(n * S_loc, B, H, 128)
+        else:
+            v4 = vt.permute(3, 0, 1, 2)  # [S,B,H,128]
         out.copy_(dit_oracle.attention_sbhd(q4, k4, v4).reshape(Sq * B, H * 128))
         return out
 
@@ -55,19 +59,22 @@ def _worker(rank, world, port, tmp):
         assert parallel.broadcast("hello" if rank == 0 else "x") == "hello"
         assert parallel.broadcast(None) is None
         # --- context-parallel attention == full attention on the gathered sequence
-        S, B, H = 48, 2, 4
-        Sl = S // world
-        q = torch.randn(S * B, H * 128, generator=g)
-        k = torch.randn(S * B, H * 128, generator=g)
-        v = torch.randn(S * B, H * 128, generator=g)
-        ref = dit_oracle.attention_sbhd(q.reshape(S, B, H, 128), k.reshape(S, B, H, 128), v.reshape(S, B, H, 128))
-        ref = ref.reshape(S * B, H * 128)
-        rows = slice(rank * Sl * B, (rank + 1) * Sl * B)
-        qkv_local = torch.cat([q[rows], k[rows], v[rows]], dim=1)  # v passed as a strided column view, like the DiT does
-        D = H * 128
-        cpa = parallel.ContextParallelAttention(group, head_groups=3, backend=_oracle_backend())  # 3 !| 4 -> falls back to 2
-        out = cpa(qkv_local[:, :D], qkv_local[:, D:2 * D], qkv_local[:, 2 * D:], Sl, B, H)
-        torch.testing.assert_close(out, ref[rows], rtol=1e-5, atol=1e-5)
+        # S_local = 24: V gathered row-major, transposed after the exchange; S_local = 64: V^T shards gathered as key segments
+        for S, B, H in ((48, 2, 4), (64 * world, 1, 4)):
+            Sl = S // world
+            q = torch.randn(S * B, H * 128, generator=g)
+            k = torch.randn(S * B, H * 128, generator=g)
+            v = torch.randn(S * B, H * 128, generator=g)
+            ref = dit_oracle.attention_sbhd(q.reshape(S, B, H, 128), k.reshape(S, B, H, 128), v.reshape(S, B, H, 128))
+            ref = ref.reshape(S * B, H * 128)
+            rows = slice(rank * Sl * B, (rank + 1) * Sl * B)
+            qkv_local = torch.cat([q[rows], k[rows], v[rows]], dim=1)  # v passed as a strided column view, like the DiT does
+            D = H * 128
+            cpa = parallel.ContextParallelAttention(group, head_groups=3, backend=_oracle_backend())  # 3 !| 4 -> falls back to 2
+            pending = cpa.start(qkv_local[:, D:2 * D], qkv_local[:, 2 * D:], Sl, B, H)
+            assert pending["segmented"] == (Sl % 64 == 0)
+            out = cpa.finish(qkv_local[:, :D], pending)
+            torch.testing.assert_close(out, ref[rows], rtol=1e-5, atol=1e-5)
         with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:
