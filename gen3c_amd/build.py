@@ -35,16 +35,19 @@ def _newer(src: Path, dst: Path, extra: list[Path]) -> bool:
     return any(p.stat().st_mtime > t for p in [src, *extra])
 
 
-def build(verbose: bool = False, force: bool = False) -> Path:
+def build(verbose: bool = False, force: bool = False, extra_flags: tuple = (), suffix: str = "") -> Path:
+    """suffix / extra_flags build an A/B copy of the library (lib/libgen3c_hip<suffix>.so) next to the product one."""
     hipcc = _hipcc()
-    OBJDIR.mkdir(parents=True, exist_ok=True)
+    objdir = LIBDIR / ("obj" + suffix)
+    lib = LIBDIR / f"libgen3c_hip{suffix}.so"
+    objdir.mkdir(parents=True, exist_ok=True)
     headers = sorted(CSRC.glob("*.hpp")) + sorted((ROOT.parent / "include").glob("*.h"))
     sources = sorted(CSRC.glob("*.hip"))
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"-I{ROOT.parent / 'include'}", "-Wall",
-             "-Wno-unused-function"]
+             "-Wno-unused-function", *extra_flags]
 
     def compile_one(src: Path) -> Path:
-        obj = OBJDIR / (src.stem + ".o")
+        obj = objdir / (src.stem + ".o")
         if force or _newer(src, obj, headers):
             cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
             if verbose:
@@ -59,14 +62,14 @@ def build(verbose: bool = False, force: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
         objs = list(ex.map(compile_one, sources))
 
-    if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    if force or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
