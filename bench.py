@@ -187,7 +187,7 @@ def main():
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        roof = dict(bound="mfma", kernel="flash_attn_fwd_v3_kernel<0,6,8>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+        roof = dict(bound="mfma", kernel="flash_attn_fwd_v3_kernel<0,6,8,true>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
                     flops_per_launch=flops_launch)
 

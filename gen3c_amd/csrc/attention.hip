@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
 constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSR = 0x100, SGB_TRANS = 0x400;
 
 // QA / QBV: VALU slots pinned behind each MFMA of region A / region B (sched_group_barrier quotas).
-template <int CTX, int QA, int QBV>
+template <int CTX, int QA, int QBV, bool FOLD>
 __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
@@ -501,6 +501,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         const bf16_t* qrow = Qb + (int64_t)(q_ok ? q_idx : 0) * p.q_row + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = q_ok ? load_bf16x8(qrow + 16 * ks) : zero_bf16x8();
+        if (FOLD) {  // FOLD: the softmax scale (in the exp2 domain) rides on Q, the running maximum on the MFMA's C operand
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = f32_to_bf16((float)qf[ks][e] * p.scale_log2);
+        }
     }
 
     // ---- LDS-DMA staging. K tile: 1024 16-B slots (row = slot>>4, chunk = slot&15); V^T tile: 1024 slots (row = slot>>3,
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             ma = max3(ma, S[0][r], S[0][r + 1]);
             mb2 = max3(mb2, S[1][r], S[1][r + 1]);
         }
-        return xor32_max(max3(ma, mb2, max3(S[0][15], S[1][15], S[1][15]))) * c;
+        return xor32_max(max3(ma, mb2, max3(S[0][15], S[1][15], S[1][15]))) * (FOLD ? 1.0f : c);
     };
     auto mask_tail = [&](f32x16 (&S)[2], int kv0) {
 #pragma unroll
@@ -597,6 +603,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     }
     if (nt == 1 && KVB > p.Skv) mask_tail(SA, 0);
     float mx_cur = row_max(SA);
+    f32x16 negm;  // FOLD: -m_run in every element: C operand of the first QK^T MFMA of a block, so scores arrive as s*c - m_run
+    if (FOLD) {   // scores are kept RELATIVE to m_run from here on; the first tile fixes m_run to its exact maximum
+        m_run = mx_cur;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) SA[mb][r] -= m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+        mx_cur = 0.f;
+    }
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
     auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, auto has_next_c, auto par_c) {
@@ -611,7 +628,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             if (t + 2 < nt) dma_k(kv0 + 2 * KVB, par);  // K(t+2) -> slot of K(t)   (last read before the previous barrier)
             dma_v(kv0 + KVB, par ^ 1);                  // V(t+1) -> slot of V(t-1)
         }
-        if (__any(mx_cur - m_run > RESCALE_THR)) {
+        if (FOLD) {
+            if (__any(mx_cur > RESCALE_THR)) {  // mx_cur is relative to m_run
+                const float delta = fmaxf(mx_cur, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S_cur[mb][r] -= delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+            }
+        } else if (__any(mx_cur - m_run > RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx_cur);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -628,7 +662,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             const int mb = sl >> 1, r0 = (sl & 1) * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S_cur[mb][r0 + j], c, neg_m));
+                const float pv = __builtin_amdgcn_exp2f(FOLD ? S_cur[mb][r0 + j] : __builtin_fmaf(S_cur[mb][r0 + j], c, neg_m));
                 psum[sl] += pv;
                 pb[sl][j] = f32_to_bf16(pv);
             }
@@ -640,14 +674,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             bf16x8 kf[4];
 #pragma unroll
             for (int i = 0; i < 3; ++i) kf[i] = load_bf16x8(cK + 32 * (i >> 3) * HD + koff[i & 7]);
+            if (!FOLD) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S_next[mb][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) S_next[mb][r] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i + 3 < 16) kf[(i + 3) & 3] = load_bf16x8(cK + 32 * ((i + 3) >> 3) * HD + koff[(i + 3) & 7]);
-                S_next[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], S_next[i >> 3], 0, 0, 0);
+                S_next[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], (FOLD && (i & 7) == 0) ? negm : S_next[i >> 3], 0, 0, 0);
                 if (i == 3) softmax_slice(0);
                 if (i == 11) softmax_slice(1);
             }
@@ -756,15 +792,16 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set = false;
-    int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined (both kept for A/B), 3 LDS-DMA + pinned interleave (default)
+    int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave (1-3 kept for A/B), 4 (default) = 3 + folded scale/max
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
-    if (vt_seg_len > 0 && variant != 3)
+    if (vt_seg_len > 0 && variant < 3)
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
     if (!attr_set) {
-        const void* fns[6] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+        const void* fns[8] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8>)};
-        for (int i = 0; i < 6; ++i) {
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>)};
+        for (int i = 0; i < 8; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -777,7 +814,8 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     // VALU quotas (6, 8) per MFMA measured best of {(4,4), (5,6), (6,8)} (profiles/r1_v5_attn_quota_ab.txt)
     if (variant == 1) G3_LAUNCH_ATTN(flash_attn_fwd_kernel<0>, flash_attn_fwd_kernel<1>);
     else if (variant == 2) G3_LAUNCH_ATTN(flash_attn_fwd_v2_kernel<0>, flash_attn_fwd_v2_kernel<1>);
-    else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8>), (flash_attn_fwd_v3_kernel<1, 6, 8>));
+    else if (variant == 3) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, false>), (flash_attn_fwd_v3_kernel<1, 6, 8, false>));
+    else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, true>));
 #undef G3_LAUNCH_ATTN
     return g3_check_launch("g3_flash_attn_fwd_bf16");
 }

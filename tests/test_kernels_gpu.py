@@ -119,12 +119,12 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["attn_v1", "attn_v2", "attn_v3"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold"])
 def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)
     yield request.param
-    ops.set_option("attn_variant", 3)
+    ops.set_option("attn_variant", 4)
 
 
 @pytest.mark.parametrize("Sq,Skv,B,H", [(256, 256, 1, 1), (512, 512, 1, 2), (300, 200, 1, 2), (96, 40, 2, 3), (1024, 512, 1, 4),

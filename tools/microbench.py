@@ -57,11 +57,11 @@ def bench_attn():
     fl = 4.0 * S * S * 128 * H
     line = []
     for rnd in range(2):
-        for variant in (1, 2, 3):
+        for variant in (3, 4):
             ops.set_option("attn_variant", variant)
             ms = timeit(lambda: ops.flash_attn(q, k, vt, S, S, 1, H, out=out), 3)
             line.append((variant, ms, fl / ms / 1e9))
-    ops.set_option("attn_variant", 3)
+    ops.set_option("attn_variant", 4)
     print(f"attn S={S} H={H}: " + "  ".join(f"[v{v} {ms:.2f}ms {tf:.0f}TF]" for v, ms, tf in line), flush=True)
     # cross attention shape
     kc = torch.randn(512, 32 * 128, device=dev).to(torch.bfloat16)
@@ -75,7 +75,7 @@ def bench_attn():
         ops.set_option("attn_variant", variant)
         ms = timeit(lambda: ops.flash_attn(qc, kc, vtc, S, 512, 1, 32, out=oc), 5)
         line.append((variant, ms, flc / ms / 1e9))
-    ops.set_option("attn_variant", 3)
+    ops.set_option("attn_variant", 4)
     print("cross-attn S=56320 M=512 H=32: " + "  ".join(f"[v{v} {ms:.3f}ms {tf:.0f}TF]" for v, ms, tf in line), flush=True)
 
 
