@@ -288,3 +288,38 @@ def test_errors_are_loud():
         ops.gemm_nt(a, w)
     with pytest.raises(_lib.Gen3cHipError):
         ops.gemm_nt(a.cpu(), w.cpu())  # no CPU fallback
+
+
+def test_dit_patchify_unpatchify_timestep_embedding():
+    """csrc/embed.hip against the torch expressions they replace (general_dit_video_conditioned.py:77-101 + blocks.py:154-159;
+    general_dit.py:348-357; blocks.py:38-57 + general_dit.py:173-177). Pure data movement must be exact."""
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, T, H, W, pt, ps = 2, 3, 8, 12, 1, 2
+    x = torch.randn(B, 16, T, H, W, device=dev, generator=g).to(torch.bfloat16)
+    m = torch.randn(B, 1, T, H, W, device=dev, generator=g).to(torch.bfloat16)
+    pose = torch.randn(B, 64, T, H, W, device=dev, generator=g).to(torch.bfloat16)
+    pad = torch.randn(B, 1, H, W, device=dev, generator=g).to(torch.bfloat16)
+    got = ops.dit_patchify([(x, True), (m, True), (pose, True), (pad, False)], B, T, H, W, pt, ps)
+    cat = torch.cat([x, m, pose, pad[:, :, None].expand(B, 1, T, H, W)], dim=1)
+    Tp, Hp, Wp = T // pt, H // ps, W // ps
+    ref = cat.view(B, -1, Tp, pt, Hp, ps, Wp, ps).permute(2, 4, 6, 0, 1, 3, 5, 7).reshape(Tp * Hp * Wp * B, -1)
+    assert torch.equal(got, ref)
+    Co = 16
+    y = torch.randn(Tp * Hp * Wp * B, ps * ps * pt * Co, device=dev, generator=g).to(torch.bfloat16)
+    got = ops.dit_unpatchify(y, B, Co, T, H, W, pt, ps)
+    ref = y.view(Tp, Hp, Wp, B, ps, ps, pt, Co).permute(3, 7, 0, 6, 1, 4, 2, 5).reshape(B, Co, T, H, W)
+    assert torch.equal(got, ref)
+    D = 4096
+    ts = torch.tensor([0.25 * math.log(80.0), 0.25 * math.log(0.002)], device=dev).to(torch.bfloat16).float()
+    w = (1.0 + 0.1 * torch.randn(D, device=dev, generator=g)).to(torch.bfloat16)
+    t_sin, emb = ops.timestep_embedding(ts.contiguous(), w, D)
+    half = D // 2
+    expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / half
+    ang = ts[:, None] * torch.exp(expo)[None]
+    ref_sin = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.bfloat16)
+    assert float((t_sin.float() - ref_sin.float()).abs().max()) <= 2 ** -7  # one bf16 ulp at |x| <= 1 (libm cos/sin/exp ulps)
+    tf = ref_sin.float()
+    ref_emb = (tf * torch.rsqrt(tf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()).to(torch.bfloat16)
+    assert _rel_l2(emb, ref_emb) < 2e-3
