@@ -29,7 +29,7 @@ def add_common_args(p: argparse.ArgumentParser) -> argparse.ArgumentParser:
     p.add_argument("--foreground_masking", action="store_true")
     p.add_argument("--save_buffer", action="store_true", help="prepend the rendered warp buffers to every frame (inference_utils.py:160-164)")
     p.add_argument("--random_init", action="store_true", help="random weights instead of checkpoints (plumbing tests)")
-    p.add_argument("--tiny", action="store_true", help="with --random_init: a small DiT/tokenizer and a 9-frame chunk (plumbing tests)")
+    p.add_argument("--tiny", action="store_true", help="a small DiT/tokenizer configuration and a 9-frame chunk (plumbing tests; with --random_init or a matching checkpoint_dir)")
     return p
 
 
@@ -43,7 +43,7 @@ class Session:
         from .tokenizer import VideoTokenizer
 
         self.args = args
-        tiny = args.tiny and args.random_init
+        tiny = args.tiny
         self.step_frames = 8 if tiny else 120
         self.chunk = self.step_frames + 1
         if args.num_video_frames is None:

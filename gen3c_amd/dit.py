@@ -8,9 +8,9 @@ cosmos_predict1/diffusion/networks/general_dit_video_conditioned.py:29-217 + gen
 like inference_utils.py:240-242 does).
 
 Nothing here computes the network in PyTorch: forward() drives the HIP kernels of libgen3c_hip.so through
-gen3c_amd.ops (GEMM/attention/norm kernels) on torch-allocated HBM buffers. What torch does do is plumbing:
-allocation, the channel concat + patch gather that feeds the embedding GEMM, and building the input-independent
-tables (RoPE cos/sin, normalised absolute position embedding) once per (shape, fps).
+gen3c_amd.ops (GEMM/attention/norm/embedding kernels) on torch-allocated HBM buffers. What torch does do is plumbing:
+allocation, context-parallel slicing of the inputs, and building the input-independent tables (RoPE cos/sin, normalised
+absolute position embedding) once per (shape, fps).
 """
 from __future__ import annotations
 

@@ -70,3 +70,51 @@ def test_video_tokenizer_interface_roundtrip_shapes():
     assert z.shape == (1, 16, 4, 4, 4)
     y = tk.decode(z)
     assert y.shape == x.shape and torch.isfinite(y.float()).all()
+
+
+def _script_archive(weights: dict, path):
+    """A TorchScript archive whose state_dict() has exactly `weights`' dotted names (what encoder.jit / decoder.jit provide to the
+    reference's loader, tokenizer/inference/utils.py:50-92)."""
+    class Node(torch.nn.Module):
+        pass
+
+    class Root(torch.nn.Module):
+        def forward(self, x: torch.Tensor) -> torch.Tensor:
+            return x
+
+    root = Root()
+    for name, w in weights.items():
+        mod = root
+        parts = name.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                setattr(mod, p, Node())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], torch.nn.Parameter(w.clone(), requires_grad=False))
+    torch.jit.script(root).save(str(path))
+
+
+def test_video_tokenizer_load_weights_from_jit_archives(tmp_path):
+    """VideoTokenizer.load_weights (pretrained_vae.py:194-214, 342-359): encoder.jit / decoder.jit TorchScript archives +
+    mean_std.pt, then encode = (net(x) - mean) / std and decode = net^-1(z * std + mean) against the reference goldens."""
+    from gen3c_amd.tokenizer import VideoTokenizer
+    dev = torch.device("cuda:0")
+    sd, x, z_ref, zin, y_ref = load_tokenizer_case()
+    enc = {k: v.float() for k, v in sd.items() if k.startswith(("encoder.", "quant_conv."))}
+    dec = {k: v.float() for k, v in sd.items() if k.startswith(("post_quant_conv.", "decoder."))}
+    assert len(enc) + len(dec) == len(sd)
+    _script_archive(enc, tmp_path / "encoder.jit")
+    _script_archive(dec, tmp_path / "decoder.jit")
+    g = torch.Generator().manual_seed(11)
+    mean, std = torch.randn(16 * 32, generator=g) * 0.1, 0.5 + torch.rand(16 * 32, generator=g)
+    torch.save((mean, std), tmp_path / "mean_std.pt")
+    tk = VideoTokenizer(pixel_chunk_duration=9, channels=16, device=dev)
+    tk.load_weights(str(tmp_path))
+    m = mean.view(16, 32)[:, :2].reshape(1, 16, 2, 1, 1)
+    s = std.view(16, 32)[:, :2].reshape(1, 16, 2, 1, 1)
+    z = tk.encode(x.to(dev))
+    rz = _rel(z, (z_ref - m) / s)
+    y = tk.decode(((zin.float() - m) / s).to(torch.bfloat16).to(dev))
+    ry = _rel(y, y_ref)
+    print(f"[tokenizer jit archives] encode rel_l2={rz:.3e} decode rel_l2={ry:.3e}")
+    assert rz <= 3e-2 and ry <= 4e-2
