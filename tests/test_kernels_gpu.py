@@ -323,3 +323,17 @@ def test_dit_patchify_unpatchify_timestep_embedding():
     tf = ref_sin.float()
     ref_emb = (tf * torch.rsqrt(tf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()).to(torch.bfloat16)
     assert _rel_l2(emb, ref_emb) < 2e-3
+
+
+def test_gemm_known_answer_constant_weights():
+    """The reference's only numeric check near this path fills projection weights with 0.1 and expects q = in_features * 0.1
+    (diffusion/training/utils/peft/lora_attn_test.py:73-250, model_channels = 256): same closed form through the MFMA GEMM."""
+    from gen3c_amd import ops
+    dev = _dev()
+    for K in (256, 4096):
+        x = torch.ones(300, K, device=dev, dtype=torch.bfloat16)
+        w = torch.full((512, K), 0.1, device=dev, dtype=torch.bfloat16)
+        out = ops.gemm_nt(x, w).float()
+        expect = K * float(torch.tensor(0.1, dtype=torch.bfloat16))  # 0.1 is rounded to bf16 once, then summed exactly in fp32
+        torch.testing.assert_close(out, torch.full_like(out, expect), rtol=1e-2, atol=0)  # rtol of the reference test
+        assert float(out.std()) == 0.0
