@@ -441,7 +441,7 @@ G3_DEVICE void phase_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI, int PH>
+template <int EPI, int PH, bool CONV>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [slot 2][region 4][128 rows][64] bf16
     const int tid = threadIdx.x;
@@ -482,7 +482,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     //   W half h : local row r <-> feature n0 + (r >> 6)*128 + h*64 + (r & 63)
     //   T half h : local row r <-> token   m0 + (r >> 5)*64  + h*32 + (r & 31)
     const int src_chunk = (tid & 7) ^ ((tid >> 4) & 7);
-    const bf16_t* src[4][2];  // [region: W0, T0, T1, W1][j]
+    const bf16_t* src[4][2];  // [region: W0, T0, T1, W1][j]   (CONV: only the W regions; token rows are gathered per tap)
+    int crd_t[2][2], crd_yx[2][2];  // CONV: per (token half, j) base input coordinates: t, and (y << 16) | (x & 0xffff)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = j * 64 + (tid >> 3);
@@ -491,16 +492,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
             const int nrow = min(n0 + (r >> 6) * 128 + h * 64 + (r & 63), p.N - 1);
             const int mrow = min(m0 + (r >> 5) * 64 + h * 32 + (r & 31), p.M - 1);
             src[h ? 3 : 0][j] = p.W + (int64_t)nrow * p.ldw + src_chunk * 8;
-            src[h ? 2 : 1][j] = p.A + (int64_t)mrow * p.lda + src_chunk * 8;
+            if (CONV) {
+                const int to = mrow / (p.cv.Ho * p.cv.Wo);
+                const int rem = mrow - to * (p.cv.Ho * p.cv.Wo);
+                const int yo = rem / p.cv.Wo;
+                const int xo = rem - yo * p.cv.Wo;
+                crd_t[h][j] = to * p.cv.st + p.cv.ot;
+                crd_yx[h][j] = ((yo * p.cv.sh + p.cv.oh) << 16) | ((xo * p.cv.sw + p.cv.ow) & 0xffff);
+                src[h ? 2 : 1][j] = nullptr;
+            } else {
+                src[h ? 2 : 1][j] = p.A + (int64_t)mrow * p.lda + src_chunk * 8;
+            }
         }
     }
+    // CONV: K tile `tile` = (tap, channel tile kc); every region is issued once per K tile in increasing order, so each keeps
+    // its own (kc, dt, dy, dx) odometer in scalars instead of dividing. Weights of tap (dt,dy,dx) start at W + tap*w_tap_stride.
+    const int nkc = CONV ? p.K / BK : 1;
+    int od_kc[4] = {0, 0, 0, 0}, od_tap[4] = {0, 0, 0, 0}, od_dt[4] = {0, 0, 0, 0}, od_dy[4] = {0, 0, 0, 0}, od_dx[4] = {0, 0, 0, 0};
     auto issue = [&](int region, int tile) __attribute__((always_inline)) {  // region compile-time after inlining
-        const int k0 = tile * BK;
         char* dst = smem_raw + ((tile & 1) << 16) + region * 16384 + wave * 1024;
+        if (!CONV) {
+            const int k0 = tile * BK;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[region][j] + k0),
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[region][j] + k0),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+            return;
+        }
+        const int k0 = od_kc[region] * BK;
+        const bool is_w = region == 0 || region == 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* a;
+            if (is_w) {
+                a = src[region][j] + (int64_t)od_tap[region] * p.cv.w_tap_stride + k0;
+            } else {
+                const int h = region - 1;
+                int ti = crd_t[h][j] + od_dt[region];
+                ti = ti < 0 ? 0 : ti;  // causal: the first frame is replicated in front
+                const int yi = (crd_yx[h][j] >> 16) + od_dy[region];
+                const int xi = (int)(short)(crd_yx[h][j] & 0xffff) + od_dx[region];
+                const bool ok = ti < p.cv.Ti && yi >= 0 && yi < p.cv.Hi && xi >= 0 && xi < p.cv.Wi;
+                a = ok ? p.A + (((int64_t)ti * p.cv.Hi + yi) * p.cv.Wi + xi) * p.lda + src_chunk * 8 + k0
+                       : reinterpret_cast<const bf16_t*>(g3_zero_page) + src_chunk * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
                                              (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+        }
+        if (++od_kc[region] == nkc) {
+            od_kc[region] = 0;
+            ++od_tap[region];
+            if (++od_dx[region] == p.cv.kw) {
+                od_dx[region] = 0;
+                if (++od_dy[region] == p.cv.kh) {
+                    od_dy[region] = 0;
+                    ++od_dt[region];
+                }
+            }
+        }
     };
 
     // ---- fragment read addresses (bytes inside a slot): row*128 + ((2 ks + g) ^ ((row >> 1) & 7))*16
@@ -520,7 +569,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     bf16x8 wf[2][4];  // current W half: [row block][k-step]
     bf16x8 tf[2][4];  // both token halves: [half][k-step]
 
-    const int nk = p.K / BK;
+    const int nk = CONV ? nkc * p.cv.ntaps : p.K / BK;
     const int nq = 4 * nk;
 
     auto read_w = [&](const char* sl, int region) __attribute__((always_inline)) {
@@ -655,16 +704,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     else store_tile<EPI>(p, acc, m0 + m_w0, n0 + n_w0, l31, g);
 }
 
-template <int EPI, int PH>
+template <int EPI, int PH, bool CONV>
 int launch_pp(const GemmParams& p, hipStream_t stream, const char* what) {
     const size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_pp_kernel<EPI, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_pp_kernel<EPI, PH, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<EPI, PH>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), smem, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<EPI, PH, CONV>), dim3(p.tiles_m * p.tiles_n), dim3(NTHREADS), smem, stream, p);
     return g3_check_launch(what);
 }
 
@@ -686,9 +735,9 @@ int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
 template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
+    if (glds && g3_opt_gemm_pingpong == 2) return launch_pp<EPI, 2, CONV>(p, stream, what);
     if constexpr (!CONV) {
-        if (glds && g3_opt_gemm_pingpong == 2) return launch_pp<EPI, 2>(p, stream, what);
-        if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI, 4>(p, stream, what);
+        if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI, 4, false>(p, stream, what);
     }
     if (g3_opt_gemm_unpinned) return glds ? launch_variant<EPI, true, CONV, false>(p, stream, what) : launch_variant<EPI, false, CONV, false>(p, stream, what);
     return glds ? launch_variant<EPI, true, CONV, true>(p, stream, what) : launch_variant<EPI, false, CONV, true>(p, stream, what);
