@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     dma_k(0, 0);
     dma_v(0, 0);
     if (nt > 1) dma_k(KVB, 1);
-    __syncthreads();
+    lds_dma_publish_barrier();
     f32x16 SA[2], SB[2];
     {
         const bf16_t* cK = sK;
@@ -601,6 +601,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
                 SA[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_bf16x8(cK + 32 * mb * HD + koff[ks]), qf[ks], SA[mb], 0, 0, 0);
         }
     }
+    // K(0)'s slot is the destination of the first LDS-DMA of the tile loop (K(2)): every wave must be done reading it. Inside the
+    // loop the end-of-tile barrier separates the reads of K(t) from the DMA of K(t+2); the prologue needs its own.
+    __syncthreads();
     if (nt == 1 && KVB > p.Skv) mask_tail(SA, 0);
     float mx_cur = row_max(SA);
     f32x16 negm;  // FOLD: -m_run in every element: C operand of the first QK^T MFMA of a block, so scores arrive as s*c - m_run
@@ -614,7 +617,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         for (int r = 0; r < 16; ++r) negm[r] = -m_run;
         mx_cur = 0.f;
     }
+#ifndef G3_AB_NO_ATTN_SETPRIO
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
     auto tile = [&](f32x16 (&S_cur)[2], f32x16 (&S_next)[2], int t, auto has_next_c, auto par_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
             mx_cur = mx_next;
         }
-        if (has_next) __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
+        if (has_next) lds_dma_publish_barrier();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
     };
 
     using True = std::integral_constant<bool, true>;

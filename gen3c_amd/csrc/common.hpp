@@ -62,4 +62,11 @@ G3_DEVICE float gelu_erf_fast(float x) {
     const float a = ((poly * t) * ex) * ax;
     return fmaxf(x, 0.0f) - a;
 }
+// Barrier that PUBLISHES LDS-DMA data (global_load_lds): the data is ordered for another wave's ds_read only by the issuing
+// wave's vmcnt wait followed by a barrier. hipcc usually emits that wait at a __syncthreads() that follows LDS-DMA, but it is
+// not obliged to (measured: it dropped it at the attention prologue) - so the wait is explicit wherever DMA data is handed over.
+G3_DEVICE void lds_dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 G3_DEVICE float silu(float x) { return x / (1.0f + __expf(-x)); }

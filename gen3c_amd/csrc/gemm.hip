@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         stage_load(0);
         stage_write(0);
     }
-    __syncthreads();
+    lds_dma_publish_barrier();
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
         }
 
         if (!STAGE_GLDS && t + 1 < nk) stage_write(buf ^ 1);
-        __syncthreads();  // with LDS-DMA in flight hipcc drains vmcnt(0) here: tile t+1 has landed for every wave
+        lds_dma_publish_barrier();  // tile t+1 has landed for every wave
     }
 
     if (p.wide_store) store_tile_lds<EPI>(p, acc, m0 + m_w0, n0 + n_w0, lane, smem_raw + wave * 16384);
@@ -425,6 +425,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
 // half-tiles in flight - everything the NEXT phase reads has landed for every wave once that barrier (plus the stagger
 // barrier) is passed; a buffer is restaged no earlier than two phases after its last ds_read.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef G3_AB_NO_GEMM_SETPRIO
+#define G3_PP_SETPRIO(x) ((void)0)
+#else
+#define G3_PP_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 template <int N> G3_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 G3_DEVICE void wait_vmcnt_rt(int halftiles) {  // tail phases: the number of half-tiles that may stay in flight
     switch (halftiles) {
@@ -609,13 +614,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
         phase_barrier();
         constexpr int ih = (P >= 2) ? 2 : 0;
         constexpr int jh = (P == 1 || P == 2) ? 1 : 0;
-        __builtin_amdgcn_s_setprio(1);
+        G3_PP_SETPRIO(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 acc[ih + i][jh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], tf[jh][ks], acc[ih + i][jh], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        G3_PP_SETPRIO(0);
         phase_barrier();
     };
     // PH == 2: one W half x both token halves (16 MFMAs) per phase, two half-tiles issued per phase. A buffer is restaged
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         phase_barrier();
         constexpr int ih = P * 2;
-        __builtin_amdgcn_s_setprio(1);
+        G3_PP_SETPRIO(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][ks], tf[j][ks], acc[ih + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        G3_PP_SETPRIO(0);
         phase_barrier();
     };
 

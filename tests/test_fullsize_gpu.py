@@ -31,7 +31,9 @@ def test_attention_full_sequence_sampled_rows_and_kv_permutation():
         sc = (q[rows, sl].float() @ k[:, sl].float().t()) / math.sqrt(HD)
         ref = torch.softmax(sc, dim=-1) @ v[:, sl].float()
         r = _rel_l2(out[rows, sl], ref)
-        assert r < 1e-2, f"head {h}: rel-L2 {r:.3e} vs fp32 reference on sampled rows"  # bf16 P and bf16 output rounding
+        # bf16 Q*scale, P and output roundings give 2.9e-3 here; a staging race in the first tiles (K read before its LDS-DMA landed,
+        # or overwritten while a late wave still reads it) showed up as 6.6e-3 on this very check
+        assert r < 4e-3, f"head {h}: rel-L2 {r:.3e} vs fp32 reference on sampled rows"
     # softmax(QK^T)V does not depend on the order of the key/value tokens
     perm = torch.randperm(S, device=dev, generator=g)
     out_p = ops.flash_attn(q, k[perm].contiguous(), ops.transpose_v(v[perm].contiguous(), S, 1, H), S, S, 1, H)

@@ -45,4 +45,21 @@ for rnd in range(3):
     for nm, lib, o in (("product", base, outs[0]), ("ab-flags", alt, outs[1])):
         ms = timeit(lambda: run(lib, o), 3)
         print(f"attention {nm:9s} {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF", flush=True)
+# the QKV GEMM shape through both libraries
+M, N, K = 56320, 12288, 4096
+a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+co = [torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)]
+
+
+def run_gemm(lib, o):
+    rc = lib.g3_gemm_bf16_nt(a.data_ptr(), K, w.data_ptr(), K, o.data_ptr(), N, M, N, K, 0, None, 1, 0, None, 0, st)
+    assert rc == 0
+
+
+for rnd in range(3):
+    for nm, lib, o in (("product", base, co[0]), ("ab-flags", alt, co[1])):
+        ms = timeit(lambda: run_gemm(lib, o), 5)
+        print(f"qkv gemm  {nm:9s} {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:6.0f} TF", flush=True)
+print("gemm outputs equal:", bool(torch.equal(co[0], co[1])))
 print("outputs equal:", bool(torch.equal(outs[0], outs[1])), " rel-l2:", float((outs[0].float() - outs[1].float()).norm() / outs[0].float().norm()))

@@ -1,0 +1,29 @@
+"""Run-to-run determinism of the attention kernels at full size (a staging race would show up as differing outputs)."""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from gen3c_amd import ops  # noqa: E402
+dev = torch.device("cuda:0")
+S, H = 56320, 8
+g = torch.Generator(device=dev).manual_seed(1)
+q = torch.randn(S, H * 128, device=dev, generator=g).to(torch.bfloat16)
+k = torch.randn(S, H * 128, device=dev, generator=g).to(torch.bfloat16)
+v = torch.randn(S, H * 128, device=dev, generator=g).to(torch.bfloat16)
+vt = ops.transpose_v(v, S, 1, H)
+for variant in (3, 4):
+    ops.set_option("attn_variant", variant)
+    outs = [ops.flash_attn(q, k, vt, S, S, 1, H).clone() for _ in range(4)]
+    torch.cuda.synchronize()
+    eq = [bool(torch.equal(outs[0], o)) for o in outs[1:]]
+    rel = [float((outs[0].float() - o.float()).norm() / outs[0].float().norm()) for o in outs[1:]]
+    print(f"variant {variant}: repeat runs equal {eq} rel-l2 {rel}  finite {bool(torch.isfinite(outs[0].float()).all())}")
+o3 = None
+for variant in (3, 4):
+    ops.set_option("attn_variant", variant)
+    o = ops.flash_attn(q, k, vt, S, S, 1, H)
+    if o3 is None:
+        o3 = o
+    else:
+        print("variant 4 vs 3 rel-l2:", float((o.float() - o3.float()).norm() / o3.float().norm()))
+ops.set_option("attn_variant", 4)
