@@ -585,10 +585,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     };
 
     // ---- prologue
+    G3_JITTER(wave, blockIdx.x + 5);
     dma_k(0, 0);
     dma_v(0, 0);
     if (nt > 1) dma_k(KVB, 1);
     lds_dma_publish_barrier();
+    G3_JITTER(wave + 2, blockIdx.x);
     f32x16 SA[2], SB[2];
     {
         const bf16_t* cK = sK;
@@ -601,9 +603,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
                 SA[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_bf16x8(cK + 32 * mb * HD + koff[ks]), qf[ks], SA[mb], 0, 0, 0);
         }
     }
+    G3_JITTER(wave + 1, blockIdx.x);
     // K(0)'s slot is the destination of the first LDS-DMA of the tile loop (K(2)): every wave must be done reading it. Inside the
     // loop the end-of-tile barrier separates the reads of K(t) from the DMA of K(t+2); the prologue needs its own.
+#ifndef G3_AB_OMIT_PROLOGUE_BARRIER  // (defined only to prove that tools/race_screen.py detects this race)
     __syncthreads();
+#endif
     if (nt == 1 && KVB > p.Skv) mask_tail(SA, 0);
     float mx_cur = row_max(SA);
     f32x16 negm;  // FOLD: -m_run in every element: C operand of the first QK^T MFMA of a block, so scores arrive as s*c - m_run
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int par = decltype(par_c)::value;
         const int kv0 = t * KVB;
+        G3_JITTER(wave + blockIdx.x, t);
         if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: redo its row max on masked scores
             mask_tail(S_cur, kv0);
             mx_cur = row_max(S_cur);
@@ -705,6 +711,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             softmax_slice(1);
         }
 
+        G3_JITTER(wave + blockIdx.x + 3, t);
         // ---- region B: O^T += V^T(t).P^T (16 MFMA, fragments 3 ahead) || softmax slices 2,3 || row max of tile t+1
         {
             const bf16_t* cV = sV + par * HD * KVB;

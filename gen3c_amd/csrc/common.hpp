@@ -62,6 +62,14 @@ G3_DEVICE float gelu_erf_fast(float x) {
     const float a = ((poly * t) * ex) * ax;
     return fmaxf(x, 0.0f) - a;
 }
+// Race screen: -DG3_AB_JITTER=<n> (tools/ab_flags.py) makes pseudo-randomly chosen waves sleep n*64 cycles at tile / phase
+// boundaries. A kernel whose LDS hand-offs are correctly fenced gives bit-identical results under any such timing.
+#ifdef G3_AB_JITTER
+#define G3_JITTER(a, b) do { if (((((int)(a)) * 7 + ((int)(b)) * 3) & 15) == 5) __builtin_amdgcn_s_sleep(G3_AB_JITTER); } while (0)
+#else
+#define G3_JITTER(a, b) ((void)0)
+#endif
+
 // Barrier that PUBLISHES LDS-DMA data (global_load_lds): the data is ordered for another wave's ds_read only by the issuing
 // wave's vmcnt wait followed by a barrier. hipcc usually emits that wait at a __syncthreads() that follows LDS-DMA, but it is
 // not obliged to (measured: it dropped it at the attention prologue) - so the wait is explicit wherever DMA data is handed over.

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_kernel(GemmParams p)
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
+        G3_JITTER(wave + blockIdx.x, t);
         if (t + 1 < nk) {
             if (STAGE_GLDS) stage_glds(t + 1, buf ^ 1);  // buf^1 was last read in iteration t-1 (barrier passed)
             else stage_load(t + 1);
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     // PH == 4: one accumulator quadrant (8 MFMAs) per phase, one half-tile issued per phase.
     auto phase4 = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
+        G3_JITTER(wave + blockIdx.x, 4 * t + P);
         constexpr bool full = decltype(FULL)::value;
         const char* sl = smem_raw + ((t & 1) << 16);
         if (P == 0) {
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_nt_pp_kernel(GemmParams
     // phase's first barrier - also for the wave group that runs a barrier behind.
     auto phase2 = [&](auto PC, auto FULL, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
+        G3_JITTER(wave + blockIdx.x, 2 * t + P);
         constexpr bool full = decltype(FULL)::value;
         const char* sl = smem_raw + ((t & 1) << 16);
         if (P == 0) {

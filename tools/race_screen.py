@@ -1,0 +1,122 @@
+"""Race screen: every LDS hand-off of the MFMA kernels must be fenced, so results may not depend on wave timing. Runs the
+product library against the same sources built with -DG3_AB_JITTER=<n> (pseudo-random waves sleep n*64 cycles at tile / phase
+boundaries) and demands BITWISE equal outputs.
+  build (here, before gpurun):  python tools/race_screen.py --build [n]
+  run (GPU box):                python tools/race_screen.py"""
+import ctypes as C
+import math
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+if "--build" in sys.argv:
+    from gen3c_amd import build
+    n = [a for a in sys.argv[1:] if a.isdigit()]
+    extra = tuple(a for a in sys.argv[1:] if a.startswith("-D"))  # e.g. -DG3_AB_OMIT_PROLOGUE_BARRIER: self-test of the screen
+    # default perturbations: sleeping waves at tile / phase boundaries AND no static wave priorities (the variant that exposed the
+    # attention prologue races of round 1; -DG3_AB_OMIT_PROLOGUE_BARRIER re-introduces one of them as a self-test of this screen)
+    jit = () if "--no-jitter" in sys.argv else (f"-DG3_AB_JITTER={n[0] if n else 30}",)
+    extra = extra + ("-DG3_AB_NO_ATTN_SETPRIO", "-DG3_AB_NO_GEMM_SETPRIO")
+    print(build.build(extra_flags=jit + extra, suffix="_ab", force=True))
+    sys.exit(0)
+
+import torch  # noqa: E402
+from gen3c_amd import _lib, ops  # noqa: E402
+
+base = _lib.load()
+alt = C.CDLL(str(ROOT / "gen3c_amd" / "lib" / "libgen3c_hip_ab.so"))
+for name, argtypes in _lib.SIGNATURES.items():
+    getattr(alt, name).argtypes = argtypes
+    getattr(alt, name).restype = _lib._RESTYPES.get(name, C.c_int)
+dev = torch.device("cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+g = torch.Generator(device=dev).manual_seed(3)
+bad = 0
+
+
+def both(fn):
+    outs = []
+    for lib in (base, alt):
+        outs.append(fn(lib))
+    torch.cuda.synchronize()
+    return outs
+
+
+def report(what, a, b):
+    global bad
+    eq = bool(torch.equal(a, b))
+    bad += not eq
+    print(f"{'ok  ' if eq else 'DIFF'} {what}" + ("" if eq else f"  rel-l2 {float((a.float() - b.float()).norm() / a.float().norm()):.3e}"), flush=True)
+
+
+# ---- attention (long and short contexts, ragged tails, segmented V^T)
+for (Sq, Skv, H, segs) in [(56320, 56320, 4, 1), (7040, 56320, 4, 8), (1000, 449, 3, 1), (56320, 512, 8, 1), (300, 128, 2, 2)]:
+    q = torch.randn(Sq, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    if segs == 1:
+        vt = ops.transpose_v(v, Skv, 1, H)
+    else:
+        sl = Skv // segs
+        vt = torch.stack([ops.transpose_v(v[i * sl:(i + 1) * sl], sl, 1, H) for i in range(segs)]).contiguous()
+    ld = vt.shape[-1]
+    for variant in (3, 4):
+        def run(lib):
+            lib.g3_set_option(b"attn_variant", variant)
+            o = torch.empty_like(q)
+            args = (q.data_ptr(), H * 128, H * 128, 128, k.data_ptr(), H * 128, H * 128, 128, vt.data_ptr(), ld, H * 128 * ld, 128 * ld)
+            tail = (o.data_ptr(), H * 128, H * 128, 128, Sq, Skv, 1, H, 128, 1.0 / math.sqrt(128), st)
+            rc = lib.g3_flash_attn_fwd_kvseg_bf16(*args, Skv // segs, H * 128 * ld, *tail) if segs > 1 else lib.g3_flash_attn_fwd_bf16(*args, *tail)
+            assert rc == 0, lib.g3_last_error()
+            return o
+        a, b = both(run)
+        report(f"attention Sq={Sq} Skv={Skv} H={H} segs={segs} variant={variant}", a, b)
+    del q, k, v, vt
+
+# ---- GEMM: every K-loop structure x epilogues x ragged shapes
+for (M, N, K, epi) in [(56320, 4096, 4096, 2), (7040, 12288, 4096, 0), (4096, 16384, 4096, 1), (3000, 4096, 16384, 2), (513, 264, 192, 3), (300, 520, 128, 0),
+                       (256, 256, 64, 0)]:
+    a_ = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w_ = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(1, N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    for pp in (0, 1, 2):
+        def run(lib):
+            lib.g3_set_option(b"gemm_pingpong", pp)
+            o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            rc = lib.g3_gemm_bf16_nt(a_.data_ptr(), K, w_.data_ptr(), K, o.data_ptr(), N, M, N, K, epi, gate.data_ptr() if epi >= 2 else None, 1, N,
+                                     res.data_ptr() if epi in (2, 4) else None, N, st)
+            assert rc == 0, lib.g3_last_error()
+            return o
+        x, y = both(run)
+        report(f"gemm {M}x{N}x{K} epi{epi} pingpong={pp}", x, y)
+    del a_, w_, gate, res
+
+# ---- implicit-GEMM convolutions (tokenizer geometries: 1x3x3, causal 3x1x1, strided)
+for (C_in, C_out, T, Hh, Ww, kt, kh, kw, st_, sh, sw) in [(128, 256, 5, 48, 64, 1, 3, 3, 1, 1, 1), (256, 256, 6, 40, 48, 3, 1, 1, 1, 1, 1), (128, 128, 5, 48, 64, 1, 3, 3, 1, 2, 2),
+                                                           (256, 256, 7, 24, 32, 3, 1, 1, 2, 1, 1)]:
+    x_ = torch.randn(T * Hh * Ww, C_in, device=dev, generator=g).to(torch.bfloat16)
+    w_ = (torch.randn(kt * kh * kw, C_out, C_in, device=dev, generator=g) / math.sqrt(C_in * kt * kh * kw)).to(torch.bfloat16)
+    bias = torch.randn(C_out, device=dev, generator=g).to(torch.bfloat16)
+    To = (T + st_ - 1) // st_ if kt == 3 else T
+    Ho, Wo = (Hh // sh, Ww // sw)
+    ot, oh, ow = (-(kt - 1), 0 if sh == 2 else -(kh // 2), 0 if sw == 2 else -(kw // 2))
+    if kt == 3 and st_ == 2:
+        To = (T - 1) // 2 + 1
+    for pp in (0, 2):
+        def run(lib):
+            lib.g3_set_option(b"gemm_pingpong", pp)
+            o = torch.empty(To * Ho * Wo, C_out, device=dev, dtype=torch.bfloat16)
+            rc = lib.g3_conv3d_cl_bf16(x_.data_ptr(), C_in, w_.data_ptr(), C_in, bias.data_ptr(), None, 0, o.data_ptr(), C_out, C_in, C_out, T, Hh, Ww, To, Ho, Wo,
+                                       kt, kh, kw, st_, sh, sw, ot, oh, ow, st)
+            assert rc == 0, lib.g3_last_error()
+            return o
+        x, y = both(run)
+        report(f"conv {C_in}->{C_out} k=({kt},{kh},{kw}) s=({st_},{sh},{sw}) on {T}x{Hh}x{Ww} pingpong={pp}", x, y)
+for lib in (base, alt):
+    lib.g3_set_option(b"attn_variant", 4)
+    lib.g3_set_option(b"gemm_pingpong", 2)
+print("RACE SCREEN", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
+sys.exit(1 if bad else 0)
