@@ -40,10 +40,34 @@ def create_parser() -> argparse.ArgumentParser:
     return p
 
 
-def _load_image(path: str, H: int, W: int) -> torch.Tensor:
+def _read_rgb(path: str) -> np.ndarray:
+    """uint8 [h,w,3]; RGBA is blended onto a white background (inference_utils.py:621-633)."""
     from PIL import Image
-    img = Image.open(path).convert("RGB").resize((W, H), Image.BICUBIC)
-    return torch.from_numpy(np.asarray(img).astype(np.float32))  # [H,W,3] 0..255
+    im = Image.open(path)
+    if im.mode == "RGBA":
+        a = np.asarray(im).astype(np.float64)
+        alpha = a[..., 3:4] / 255.0
+        return (a[..., :3] * alpha + 255.0 * (1 - alpha)).astype(np.uint8)
+    return np.asarray(im.convert("RGB"))
+
+
+def load_condition_image(path: str, H: int, W: int) -> torch.Tensor:
+    """The seeding frame exactly as read_video_or_image_into_frames_BCTHW prepares it (inference_utils.py:597-660):
+    uint8 / 128 - 1 -> bf16 -> torchvision resize(BICUBIC, antialias=True) (= F.interpolate in fp32, cast back) -> [1,3,1,H,W] bf16."""
+    x = torch.from_numpy(_read_rgb(path) / 128.0 - 1.0).permute(2, 0, 1)[None].to(torch.bfloat16)
+    if tuple(x.shape[-2:]) != (H, W):
+        x = torch.nn.functional.interpolate(x.float(), size=(H, W), mode="bicubic", antialias=True, align_corners=False).to(torch.bfloat16)
+    return x[:, :, None]
+
+
+def load_cache_image(path: str, H: int, W: int) -> torch.Tensor:
+    """The image the 3D cache is built from, as _predict_moge_depth prepares it (gen3c_single_image.py:118-180): OpenCV bilinear
+    resize to 1280x720 on uint8, / 255, bilinear resize to (H, W), * 2 - 1 -> [1,3,H,W] fp32. (cv2.INTER_LINEAR is the
+    half-pixel, non-antialiased bilinear of F.interpolate(align_corners=False); its uint8 output rounding is reproduced.)"""
+    x = torch.from_numpy(_read_rgb(path).astype(np.float32)).permute(2, 0, 1)[None]
+    x = torch.nn.functional.interpolate(x, size=(720, 1280), mode="bilinear", align_corners=False).round().clamp(0, 255) / 255.0
+    x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=False)
+    return x * 2 - 1
 
 
 def _resolve_depth_fn(spec: str, cache):
@@ -70,8 +94,7 @@ def demo(args) -> np.ndarray:
     dev, H, W = ses.dev, args.height, args.width
 
     # ---- inputs: image, depth (MoGe stand-in), intrinsics
-    img255 = _load_image(args.input_image_path, H, W).to(dev)
-    image = (img255.permute(2, 0, 1) / 255.0 * 2 - 1)[None]                       # renders use x/255*2-1 (gen3c_single_image.py:135)
+    image = load_cache_image(args.input_image_path, H, W).to(dev)                 # renders use x/255*2-1 (gen3c_single_image.py:135,176)
     z = np.load(args.depth_path)
     depth = torch.from_numpy(np.asarray(z["depth"], dtype=np.float32)).to(dev)
     if depth.shape != (H, W):
@@ -101,7 +124,7 @@ def demo(args) -> np.ndarray:
             cache.update_cache(new_image=last01[None] * 2 - 1, new_depth=pred_depth, new_w2c=w2cs[:, start], new_intrinsics=Ks[:, start])
         return cache.render_cache(w2cs[:, start:start + ses.chunk], Ks[:, start:start + ses.chunk])
 
-    cond_image = (img255.permute(2, 0, 1) / 128.0 - 1.0)[None, :, None]   # condition image uses x/128-1 (inference_utils.py:648)
+    cond_image = load_condition_image(args.input_image_path, H, W)          # condition image uses x/128-1 (inference_utils.py:648)
     video = ses.finalize(ses.run_chunks(cond_image, render))
     ses.save(video)
     return video
