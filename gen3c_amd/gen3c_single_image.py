@@ -97,9 +97,9 @@ def demo(args) -> np.ndarray:
     image = load_cache_image(args.input_image_path, H, W).to(dev)                 # renders use x/255*2-1 (gen3c_single_image.py:135,176)
     z = np.load(args.depth_path)
     depth = torch.from_numpy(np.asarray(z["depth"], dtype=np.float32)).to(dev)
-    if depth.shape != (H, W):
-        depth = torch.nn.functional.interpolate(depth[None, None], size=(H, W), mode="nearest")[0, 0]
-    depth = torch.where(torch.isfinite(depth) & (depth > 0), depth, torch.full_like(depth, 1000.0))  # invalid -> 1000 (:141)
+    depth = torch.where(torch.isfinite(depth) & (depth > 0), depth, torch.full_like(depth, 1000.0))  # invalid -> 1000 (:141), then
+    if depth.shape != (H, W):                                                                            # bilinear to the target (:153-158)
+        depth = torch.nn.functional.interpolate(depth[None, None], size=(H, W), mode="bilinear", align_corners=False)[0, 0]
     if "intrinsics" in z.files:
         K = torch.from_numpy(np.asarray(z["intrinsics"], dtype=np.float32)).to(dev)
     else:
