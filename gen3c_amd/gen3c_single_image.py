@@ -110,8 +110,7 @@ def demo(args) -> np.ndarray:
                                     generator=torch.Generator(device=dev).manual_seed(args.seed), input_image=image, input_depth=depth[None, None],
                                     input_w2c=w2c0[None], input_intrinsics=K[None], filter_points_threshold=args.filter_points_threshold,
                                     foreground_masking=args.foreground_masking, input_format=["B", "C", "H", "W"])
-    valid = depth[depth < 100]
-    center_depth = float(torch.quantile(valid.flatten()[:: max(1, valid.numel() // 100000)], 0.5)) if valid.numel() else 1.0
+    center_depth = 1.0  # the reference passes this constant (gen3c_single_image.py:340-349)
     traj = "left" if args.trajectory == "none" else args.trajectory
     dist_ = 0.0 if args.trajectory == "none" else args.movement_distance
     w2cs, Ks = generate_camera_trajectory(traj, w2c0, K, args.num_video_frames, dist_, args.camera_rotation, center_depth=center_depth, device=dev)
