@@ -17,3 +17,17 @@ def test_context_parallel_step_matches_single_rank():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "[cp_check] OK" in r.stdout
+
+
+def test_context_parallel_code_path_over_rccl_single_rank():
+    """The same check with backend "nccl" (= RCCL) and ONE rank: RCCL refuses two ranks on one GPU, but a 1-rank group still runs
+    every collective call of the context-parallel path (async all_gather_into_tensor of K and the V^T shards, Work.wait(), the
+    NCCL-stream / compute-stream hand-off) through the real RCCL process group."""
+    import os
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", str(ROOT / "tools" / "cp_check.py")]
+    env = dict(os.environ, G3_CP_CHECK_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=env)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "[cp_check] OK" in r.stdout

@@ -21,7 +21,8 @@ from gen3c_amd.sampler import Gen3CDenoiser, VideoExtendCondition, add_condition
 
 def main():
     torch.cuda.set_device(0)
-    init_distributed("gloo")
+    backend = os.environ.get("G3_CP_CHECK_BACKEND", "gloo")  # "nccl" works with ONE rank only on a 1-GPU box (API-path smoke)
+    init_distributed(backend)
     world, rank = dist.get_world_size(), dist.get_rank()
     parallel_state.initialize_model_parallel(context_parallel_size=world)
     dev = torch.device("cuda:0")
@@ -51,7 +52,7 @@ def main():
     rel = float((part.float() - ref).norm() / ref.norm())
     mx = float((part.float() - ref).abs().max())
     print(f"[cp_check] rank {rank}/{world}: CP vs non-CP denoise step rel_l2={rel:.3e} max_abs={mx:.3e}", flush=True)
-    ok = torch.tensor([1.0 if (rel < 5e-3 and np.isfinite(rel)) else 0.0])
+    ok = torch.tensor([1.0 if (rel < 5e-3 and np.isfinite(rel)) else 0.0], device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     if ok.item() != 1.0:
