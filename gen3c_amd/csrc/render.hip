@@ -65,7 +65,14 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const float* __restri
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(group_max + item / group_size, __float_as_uint(local_max));  // non-negative floats order like uints
+    // one atomic per WORKGROUP: thousands of same-address atomics per item serialise in the L2 (they were most of this kernel's time)
+    __shared__ float wave_max[4];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = local_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(group_max + item / group_size, __float_as_uint(m));  // non-negative floats order like uints
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -465,7 +472,7 @@ extern "C" int g3_warp_project_f32(const float* points, const float* w2c, const 
                                    int group_size, void* stream) {
     if (!points || !w2c || !K || !z || !flow || !maskz || !group_max) return g3_set_error(G3_ERR_ARG, "g3_warp_project_f32: null operand");
     if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_project_f32: bad shape");
-    hipLaunchKernelGGL(warp_project_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, points, w2c, K, mask1, z,
+    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, (hipStream_t)stream, points, w2c, K, mask1, z,
                        flow, cam_points, maskz, (unsigned*)group_max, n, h, w, group_size);
     return g3_check_launch("g3_warp_project_f32");
 }
