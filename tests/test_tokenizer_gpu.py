@@ -118,3 +118,18 @@ def test_video_tokenizer_load_weights_from_jit_archives(tmp_path):
     ry = _rel(y, y_ref)
     print(f"[tokenizer jit archives] encode rel_l2={rz:.3e} decode rel_l2={ry:.3e}")
     assert rz <= 3e-2 and ry <= 4e-2
+
+
+@pytest.mark.parametrize("rows,n,ld", [(37, 14080, 14080), (16, 1024, 1100 // 8 * 8), (5, 16392, 16392), (9, 100, 104), (3, 16384, 16384)])
+def test_softmax_rows_both_paths(rows, n, ld):
+    """g3_softmax_rows_bf16: register-resident path (n <= 16384, n % 8 == 0) and the streaming path, against torch fp32."""
+    from gen3c_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(rows + n)
+    x = (torch.randn(rows, ld, device=dev, generator=g) * 3).to(torch.bfloat16)
+    ref = torch.softmax(x[:, :n].float() * 0.37, dim=-1)
+    y = x.clone()
+    _lib.check(_lib.load().g3_softmax_rows_bf16(y.data_ptr(), ld, rows, n, 0.37, torch.cuda.current_stream().cuda_stream), "softmax")
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, n:], x[:, n:])  # padding columns untouched
+    assert _rel(y[:, :n], ref) < 4e-3 and float((y[:, :n].float().sum(-1) - 1).abs().max()) < 2e-2
