@@ -809,11 +809,11 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     if (vt_seg_len > 0 && variant < 3)
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
     if (!attr_set) {
-        const void* fns[7] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+        const void* fns[8] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>)};
-        for (int i = 0; i < 7; ++i) {
+                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>)};
+        for (int i = 0; i < 8; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -827,6 +827,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     if (variant == 1) G3_LAUNCH_ATTN(flash_attn_fwd_kernel<0>, flash_attn_fwd_kernel<1>);
     else if (variant == 2) G3_LAUNCH_ATTN(flash_attn_fwd_v2_kernel<0>, flash_attn_fwd_v2_kernel<1>);
     else if (variant == 3) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, false>), (flash_attn_fwd_v3_kernel<1, 6, 8, false>));
+    else if (variant == 5) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, true>));  // tests: folded arithmetic at every length
     else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, false>));  // short contexts: the fold's prologue does not pay
 #undef G3_LAUNCH_ATTN
     return g3_check_launch("g3_flash_attn_fwd_bf16");

@@ -119,7 +119,7 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
-@pytest.fixture(params=[1, 2, 3, 4], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all"])
 def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)
@@ -191,6 +191,29 @@ def test_flash_attn_strided_views_and_zero_context_rows(attn_variant):
     ref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), Sq, Skv, B, H)
     _report("attn strided", out, ref)
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_flash_attn_folded_long_context_edges():
+    """The folded kernel (scale on Q, running max as the MFMA C operand) on long contexts with the awkward cases: ragged last tile,
+    a late key whose score jumps far above the running maximum (rescale branch shifts the pending scores), large-magnitude scores,
+    batch > 1 and strided q/k/v views."""
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(99)
+    for (Sq, Skv, B, H, qscale, spike) in [(200, 4161, 1, 2, 1.0, None), (256, 3000, 2, 2, 1.0, 2900), (96, 2600, 1, 1, 6.0, 2500), (320, 8256, 1, 3, 1.0, 40)]:
+        W = H * 128
+        big = torch.randn(max(Sq, Skv) * B, 3 * W, device=dev, generator=g).to(torch.bfloat16)
+        q, k, v = big[:Sq * B, :W] * qscale, big[:Skv * B, W:2 * W], big[:Skv * B, 2 * W:]
+        q = q.to(torch.bfloat16)
+        if spike is not None:  # one key aligned with every query: its score towers over the rest
+            k = k.clone()
+            k.view(Skv, B, H, 128)[spike] = (q.view(Sq, B, H, 128).float().mean(0) * 4).to(torch.bfloat16)
+        out = ops.flash_attn(q, k, ops.transpose_v(v, Skv, B, H), Sq, Skv, B, H)
+        q4, k4, v4 = (t.float().reshape(-1, B, H, 128).permute(1, 2, 0, 3) for t in (q, k, v))
+        ref = (torch.softmax(q4 @ k4.transpose(-1, -2) / math.sqrt(128), -1) @ v4).permute(2, 0, 1, 3).reshape(Sq * B, W)
+        r = _rel_l2(out, ref)
+        print(f"[attn folded edges Sq={Sq} Skv={Skv} B={B} H={H}] rel_l2={r:.3e}")
+        assert torch.isfinite(out.float()).all() and r < 1e-2
 
 
 def test_flash_attn_segmented_vt_matches_plain():
