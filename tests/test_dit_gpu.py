@@ -44,3 +44,37 @@ def test_dit_forward_matches_reference_golden(name):
     assert torch.isfinite(y).all()
     assert rel <= 2e-2
     assert mx <= 6e-2 * float(y_ref.abs().max())
+
+
+def test_dit_forward_long_sequence_vs_oracle():
+    """2 304 tokens (> 2 048): the self-attention launches take the long-context (folded) kernel, the GEMMs the ping-pong K loop
+    with M not a multiple of the tile; random-init weights (with non-zero AdaLN) against the fp32 oracle on the same bf16 values."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    from oracle import dit_oracle
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(max_img_h=48, max_img_w=48, max_frames=16, in_channels=81, model_channels=256, num_blocks=2, num_heads=2,
+                                adaln_lora_dim=32, crossattn_emb_channels=128, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=21)
+    B, T, H, W, M = 1, 4, 48, 48, 32   # 4 x 24 x 24 = 2304 tokens
+    g = torch.Generator().manual_seed(4)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(B, 16, T, H, W).to(torch.bfloat16)
+    mask = torch.zeros(B, 1, T, H, W, dtype=torch.bfloat16)
+    mask[:, :, :1] = 1
+    pose = (0.5 * rnd(B, 64, T, H, W)).to(torch.bfloat16)
+    ctx = (0.2 * rnd(B, M, 128)).to(torch.bfloat16)
+    ts = torch.tensor([0.7], dtype=torch.bfloat16)
+    pad = torch.zeros(B, 1, 8 * H, 8 * W, dtype=torch.bfloat16)
+    y = net(x=x.to(dev), timesteps=ts.to(dev), crossattn_emb=ctx.to(dev), crossattn_mask=None, fps=torch.tensor([24.0], device=dev),
+            padding_mask=pad.to(dev), condition_video_indicator=mask[:, :, :, :1, :1].to(dev), condition_video_input_mask=mask.to(dev),
+            condition_video_pose=pose.to(dev))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    y_ref = dit_oracle.dit_forward(sd, x.float(), ts.float(), ctx.float(), mask.float(), pose.float(), pad.float(), torch.tensor([24.0]),
+                                   num_blocks=2, num_heads=2)
+    y = y.float().cpu()
+    rel = float((y - y_ref).norm() / y_ref.norm())
+    mx = float((y - y_ref).abs().max())
+    print(f"[dit 2304 tokens] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
+    assert y.shape == y_ref.shape and torch.isfinite(y).all()
+    assert rel <= 2e-2 and mx <= 6e-2 * float(y_ref.abs().max())
