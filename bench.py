@@ -191,6 +191,16 @@ def main():
                     frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
                     flops_per_launch=flops_launch)
 
+    # second MFMA kernel: the block GEMMs (ping-pong kernel), same live hipEvent timing; reported next to `roofline`
+    gemms = [(meta, tm.elapsed_ms()) for (name, meta, tm) in timers if name == "gemm_nt"]
+    roof_gemm = None
+    if gemms:
+        g_ms = sum(ms for _, ms in gemms)
+        g_fl = sum(2.0 * m["M"] * m["N"] * m["K"] for m, _ in gemms)
+        roof_gemm = dict(bound="mfma", kernel="gemm_bf16_nt_pp_kernel<EPI,2,false>", achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
+                         unit="TFLOP/s", frac=round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), launches=len(gemms),
+                         total_ms_per_step=round(g_ms / args.steps, 2))
+
     if rank == 0:
         step_flops = 2 * dit_forward_flops(N_tok, L=args.blocks)
         ms_per_step = elapsed / args.steps * 1e3
@@ -207,6 +217,7 @@ def main():
             "step_mfma_frac": round(step_flops / (elapsed / args.steps) / 1e12 / world / PEAK_BF16_TFLOPS, 4),
             "output_finite": finite,
             "roofline": roof,
+            "roofline_gemm": roof_gemm,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -72,8 +72,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None
         assert (rm, rn) == (M, N)
         rp = _dev(residual, "residual")
     lib = _lib.load()
+    timer = None
+    if _KERNEL_TIMERS is not None and M >= 4096:  # the block GEMMs; tiny ones (context K/V, embeddings of a few rows) are not worth an event pair
+        timer = HipTimer()
+        timer.start()
     _lib.check(lib.g3_gemm_bf16_nt(_dev(a, "a"), lda, _dev(w, "w"), ldw, _dev(out, "out"), ldc, M, N, K, epilogue, gp, grows,
                                    ldg, rp, ldr, _stream()), "g3_gemm_bf16_nt")
+    if timer is not None:
+        timer.stop()
+        _KERNEL_TIMERS.append(("gemm_nt", dict(M=M, N=N, K=K, epilogue=epilogue), timer))
     return out
 
 
