@@ -6,8 +6,14 @@ build the network input, net(cond), net(uncond), CFG, conditioning-frame replace
 121x704x1280 video latent [1,16,16,88,160] (56 320 tokens), random-init Cosmos-7B weights (28 blocks x 4096, 32 heads),
 synthetic conditions of SURVEY.md 8d. Inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU,
-                                                            context parallel over the 16 latent frames via RCCL)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N>1 = context parallel over the 16 latent frames, one process per GPU over RCCL. Both launch forms work:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`): RANK / WORLD_SIZE come
+    from the environment;
+  * bare (`python bench.py --gpus N`): no WORLD_SIZE in the environment -> this process re-executes itself under
+    `torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (self_launch_argv), the counterpart of the
+    reference's `torchrun --nproc_per_node=N gen3c_single_image.py --num_gpus N` (gen3c_single_image.py:248-255).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -82,7 +88,18 @@ def cpu_baseline(threads: int):
                        f"extrapolated by FLOPs to the 4.419 PFLOP step")
 
 
-def main():
+def self_launch_argv(n_gpus: int, argv: list, port: int | None = None) -> list:
+    """Command line that runs this script as `n_gpus` ranks of one node (used when bench.py is started bare with --gpus N>1)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:  # a free rendezvous port (hard-coded ports collide on shared boxes)
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -90,7 +107,21 @@ def main():
     ap.add_argument("--blocks", type=int, default=28, help="(debug only) number of DiT blocks; anything but 28 is not the benchmark")
     ap.add_argument("--latent", type=str, default="16,88,160", help="(debug only) latent T,H,W")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL) and relay rank 0's JSON line
+        share = os.environ.get("G3_BENCH_SHARE_GPU") == "1"  # plumbing runs on a 1-GPU box (all ranks on cuda:0, gloo)
+        if not share and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible on this node")
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this driver
+        env.setdefault("OMP_NUM_THREADS", "8")
+        sys.exit(subprocess.call(self_launch_argv(args.gpus, sys.argv[1:]), env=env))
 
     from gen3c_amd import ops
     from gen3c_amd.dit import VideoExtendGeneralDIT
@@ -106,6 +137,8 @@ def main():
         local = init_distributed(os.environ.get("G3_BENCH_BACKEND", "nccl"))
         if os.environ.get("G3_BENCH_SHARE_GPU") == "1":
             local = 0
+        elif torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one GPU per rank is required)")
         torch.cuda.set_device(local)
         parallel_state.initialize_model_parallel(context_parallel_size=world)
     else:
@@ -207,7 +240,8 @@ def main():
         value = args.steps / elapsed
         out = {
             "metric": "denoise-steps/sec (121x1280x704 latent, Cosmos-7B)", "value": round(value, 5), "unit": "denoise-steps/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"GEN3C-Cosmos-7B denoise step: 2 DiT forwards (cond+uncond) + CFG + latent replace + Euler on latent "
                                    f"[1,16,{T},{Hl},{Wl}] = {N_tok} tokens, {args.blocks} blocks x 4096, 32 heads, guidance=1, 35-step Karras schedule, "
