@@ -71,13 +71,22 @@ class DiffusionGen3CModel:
 
     # ---- conditions
     def _text_conditions(self, data_batch: dict, is_negative_prompt: bool) -> Tuple[VideoExtendCondition, VideoExtendCondition]:
-        """video_cond conditioner: `get_condition_with_negative_prompt` / `get_condition_uncondition`
-        (conditioner.py:234-292): text dropout for the unconditional branch = all-zero embeddings."""
+        """The `video_cond` conditioner's two builders (conditioner.py:234-292, config/base/conditioner.py:27-30):
+          * is_negative_prompt=True  = `get_condition_with_negative_prompt`: the TextAttr embedder is NOT dropped for the
+            unconditional branch (dropout 0); its input is `neg_t5_text_embeddings` / `neg_t5_text_mask` when the batch carries a
+            tensor under that key, otherwise the batch's own (positive) text - this is what Gen3cPipeline always uses
+            (gen3c_pipeline.py:250);
+          * is_negative_prompt=False = `get_condition_uncondition`: text dropout rate 0.2 > 1e-4 -> rate 1 -> all-zero
+            embeddings for the unconditional branch (the mask is never dropped, conditioner.py:102-103)."""
         common = dict(crossattn_mask=data_batch.get("t5_text_mask"), padding_mask=data_batch.get("padding_mask"),
                       fps=data_batch.get("fps"), num_frames=data_batch.get("num_frames"), image_size=data_batch.get("image_size"))
         cond = VideoExtendCondition(crossattn_emb=data_batch["t5_text_embeddings"], **common)
-        if is_negative_prompt and isinstance(data_batch.get("neg_t5_text_embeddings"), torch.Tensor):
-            un = VideoExtendCondition(crossattn_emb=data_batch["neg_t5_text_embeddings"], **{**common, "crossattn_mask": data_batch.get("neg_t5_text_mask")})
+        if is_negative_prompt:
+            if isinstance(data_batch.get("neg_t5_text_embeddings"), torch.Tensor):
+                un = VideoExtendCondition(crossattn_emb=data_batch["neg_t5_text_embeddings"],
+                                          **{**common, "crossattn_mask": data_batch.get("neg_t5_text_mask")})
+            else:
+                un = VideoExtendCondition(crossattn_emb=data_batch["t5_text_embeddings"], **common)
         else:
             un = VideoExtendCondition(crossattn_emb=torch.zeros_like(data_batch["t5_text_embeddings"]), **common)
         return cond, un
@@ -196,7 +205,8 @@ class Gen3cPipeline:
         batch = prepare_data_batch(self.height, self.width, self.num_video_frames, self.fps, prompt_embedding, negative_prompt_embedding, dev)
         batch["condition_state"] = rendered_warp_images.to(dev)
         batch["condition_state_mask"] = rendered_warp_masks.to(dev)
-        sample = generate_world_from_video(self.model, self.model.state_shape, negative_prompt_embedding is not None, batch, self.guidance,
+        # is_negative_prompt=True unconditionally, as Gen3cPipeline._run_model does (gen3c_pipeline.py:247-251)
+        sample = generate_world_from_video(self.model, self.model.state_shape, True, batch, self.guidance,
                                            self.num_steps, self.seed, condition_latent, 1, xt=xt)
         video = (1.0 + self.model.decode(sample)).clamp(0, 2) / 2  # world_generation_pipeline.py:244-245
         return (video[0].permute(1, 2, 3, 0) * 255).to(torch.uint8).cpu().numpy()
