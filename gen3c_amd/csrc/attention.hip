@@ -24,6 +24,7 @@
 //     K/V^T panels.
 #include "common.hpp"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -803,12 +804,31 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
-    static bool attr_set = false;
+    static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
+    static std::mutex attr_mu;
     int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave (1-3 kept for A/B), 4 (default) = 3 + folded scale/max
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
+    if (variant >= 3) {
+        // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
+        // offsets it forms must stay below 4 GiB, otherwise they wrap silently (e.g. a strided K view of a fused [S*B, 3*4096]
+        // QKV buffer at B >= 4). Out-of-range problems run on v2 (64-bit addressing) when V^T is not segmented.
+        const uint64_t k_max = (uint64_t)(Skv - 1 + 2 * KVB) * (uint64_t)k_row * 2u + 256u;
+        const uint64_t n_seg = vt_seg_len > 0 ? (uint64_t)(Skv / vt_seg_len) : 1u;
+        const uint64_t v_max = (uint64_t)(HD - 1) * (uint64_t)vt_row * 2u + (n_seg - 1) * (uint64_t)vt_seg_stride * 2u + ((uint64_t)kv_span + KVB) * 2u + 256u;
+        if (k_max > 0xFFFFFFFFull || v_max > 0xFFFFFFFFull) {
+            if (vt_seg_len > 0)
+                return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: K / V^T span exceeds the kernel's 32-bit byte offsets (k %llu, vt %llu bytes)",
+                                    (unsigned long long)k_max, (unsigned long long)v_max);
+            variant = 2;
+        }
+    }
     if (vt_seg_len > 0 && variant < 3)
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
-    if (!attr_set) {
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipGetDevice failed");
+    {
+      std::lock_guard<std::mutex> attr_lock(attr_mu);
+      if (!attr_set[dev_id]) {
         const void* fns[8] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
@@ -817,7 +837,8 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_set[dev_id] = true;
+      }
     }
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;

@@ -217,11 +217,28 @@ class VideoExtendGeneralDIT(nn.Module):
         self._tables.clear()
         return out
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .bfloat16() move or re-create the parameters: the fused weight copies and the cached tables would be
+        # stale (or on the old device)
+        out = super()._apply(fn, *args, **kwargs)
+        self._packed = None
+        self._tables.clear()
+        return out
+
+    def _weights_key(self) -> tuple:
+        """Identity of the current weight set: (storage address, in-place version counter) of every parameter. Any in-place
+        update (p.copy_, weight swapping) or re-assignment (load_state_dict(assign=True) on a sub-module) changes it."""
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     # ------------------------------------------------------------------------------------------------ weight packing
     def _pack(self):
-        """Fuse per-layer projection weights that share an input into one GEMM operand (done once per weight set)."""
-        if self._packed is not None:
+        """Fuse per-layer projection weights that share an input into one GEMM operand (done once per weight set; rebuilt when
+        a parameter was replaced or modified in place since)."""
+        key = self._weights_key()
+        if self._packed is not None and self._packed["key"] == key:
             return self._packed
+        if self._packed is not None:
+            self._tables.clear()  # the position tables derive from the pos-emb parameters
         P = dict(self.named_parameters())
         blocks = []
         for i in range(self.num_blocks):
@@ -239,7 +256,7 @@ class VideoExtendGeneralDIT(nn.Module):
                 w1=P[f"{mlp}.block.layer1.weight"], w2=P[f"{mlp}.block.layer2.weight"],
                 ada=[(P[f"{pre}.{j}.adaLN_modulation.1.weight"], P[f"{pre}.{j}.adaLN_modulation.2.weight"]) for j in range(3)],
             ))
-        self._packed = dict(blocks=blocks, P=P)
+        self._packed = dict(blocks=blocks, P=P, key=key)
         return self._packed
 
     # ------------------------------------------------------------------------------------------------ context parallel

@@ -188,7 +188,36 @@ def ray_triangle_depth(rays: np.ndarray, tris: np.ndarray, eps: float = 1e-8, ch
     return np.where(best < F32(1e10), best, F32(0)).reshape(h, w).astype(F32)
 
 
-def forward_warp(frame1, mask1, world_points1, w2c, K, render_depth=False, foreground_masking=False, boundary_mask=None):
+_RAY_TRI_LIB = None
+
+
+def ray_triangle_depth_c(rays: np.ndarray, tris: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """Same function as ray_triangle_depth, evaluated by the plain-C brute force of oracle/c/ray_tri.c (OpenMP over rays; identical
+    fp32 operation order, bit-identical results - tests/test_warp_oracle_golden.py). Used at sizes where the numpy version needs
+    minutes (704x1280 rays x thousands of triangles). Builds oracle/_build/libray_tri.so with gcc on first use if it is missing."""
+    global _RAY_TRI_LIB
+    import ctypes as C
+    from pathlib import Path
+    if _RAY_TRI_LIB is None:
+        here = Path(__file__).resolve().parent
+        so = here / "_build" / "libray_tri.so"
+        if not so.exists():
+            import subprocess
+            subprocess.run(["make", "-C", str(here / "c")], check=True, capture_output=True)
+        lib = C.CDLL(str(so))
+        lib.g3o_ray_triangle_depth.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+        lib.g3o_ray_triangle_depth.restype = None
+        _RAY_TRI_LIB = lib
+    h, w, _ = rays.shape
+    r = np.ascontiguousarray(rays, dtype=F32).reshape(-1, 3)
+    t3 = np.ascontiguousarray(tris, dtype=F32).reshape(-1, 9)
+    out = np.empty((h * w,), F32)
+    _RAY_TRI_LIB.g3o_ray_triangle_depth(r.ctypes.data, r.shape[0], t3.ctypes.data, t3.shape[0], float(eps), out.ctypes.data)
+    return out.reshape(h, w)
+
+
+def forward_warp(frame1, mask1, world_points1, w2c, K, render_depth=False, foreground_masking=False, boundary_mask=None,
+                 ray_triangle_fn=None):
     """forward_warp for the cache path (depth1=None, world points given; cache_3d.py:202-214 calls it with
     intrinsic1 = intrinsic2 = target K). Returns (warped_frame2, mask2, warped_depth2 or None, flow12, idx)."""
     frame1 = _f(frame1)
@@ -208,7 +237,7 @@ def forward_warp(frame1, mask1, world_points1, w2c, K, render_depth=False, foreg
             if len(tris) == 0:
                 continue
             rays = camera_rays(h, w, K[i])
-            t = ray_triangle_depth(rays, tris)
+            t = (ray_triangle_fn or ray_triangle_depth)(rays, tris)
             mesh_z = (t * rays[..., 2]).astype(F32)
             closer = ((mesh_z + F32(0.02)).astype(F32) < depth2[i]) & (mesh_z > 0)
             keep = (~closer).astype(F32)

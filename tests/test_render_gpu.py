@@ -102,6 +102,62 @@ def test_render_cache_full_resolution_vs_oracle():
     assert bad.mean() < 1e-5 and err.max() < 5e-2
 
 
+def _cam(tx=0.0, ty=0.0, tz=0.0, yaw=0.0):
+    M = np.eye(4, dtype=np.float32)
+    c, s = np.cos(yaw), np.sin(yaw)
+    M[:3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    M[:3, 3] = [tx, ty, tz]
+    return M
+
+
+def test_foreground_masking_full_resolution_vs_bruteforce_oracle():
+    """BASELINE config 5 runs `--foreground_masking` at 704x1280: forward_warp(foreground_masking=True) on one reference pair
+    (forward_warp_utils_pytorch.py:286-334) against the oracle, whose ray/triangle depth is the BRUTE FORCE over all
+    901 120 rays x ~2 256 boundary triangles (oracle/c/ray_tri.c, the plain-C restatement of ray_triangle_intersection_warp.py:23-105)
+    - no bounding boxes, so the kernel's conservative rasteriser is checked, not mirrored. Item 0: a large lateral move that drags
+    the foreground disc's boundary mesh across the left image border; item 1: a camera plane that cuts through the 'skirt' of boundary
+    triangles between the foreground disc (z 1.6) and the background (z 4): 780 triangles have a vertex behind the camera, 526 straddle
+    z = 0, while 71 % of the frame stays valid. Masks bit-exact."""
+    from gen3c_amd import renderer
+    from oracle import warp_oracle as wo
+    dev = torch.device("cuda:0")
+    h, w = 704, 1280
+    depth, img, K = _scene(h, w)
+    pts = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    rel = wo.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    bnd = ~wo.reliable_depth_mask(depth[None, None])[0, 0]
+    w2cs = np.stack([_cam(tx=-0.5), _cam(tx=-0.7, tz=-1.68)])
+    Ks = np.broadcast_to(K[None], (2, 3, 3)).copy()
+    # geometry of the case (so that a silent change of the scene cannot hollow the test out)
+    _, camp = wo.project_points(np.broadcast_to(pts, (2, h, w, 3)), w2cs, Ks)
+    tri_z = [wo.mesh_triangles(*wo.downsample_points_mask(camp[i], bnd, 4))[..., 2] for i in range(2)]
+    n_behind = int((tri_z[1].min(1) <= 1e-4).sum())
+    n_straddle = int(((tri_z[1].min(1) <= 1e-4) & (tri_z[1].max(1) > 1e-4)).sum())
+    assert len(tri_z[0]) > 2000 and n_behind > 100 and n_straddle > 50, (len(tri_z[0]), n_behind, n_straddle)
+
+    imgs = _t(np.broadcast_to(img[None], (2, 3, h, w)).copy(), dev)
+    frame, m2, d2, flow = renderer.forward_warp(imgs, _t(np.broadcast_to(rel, (2, 1, h, w)).copy(), dev), None, None, _t(w2cs, dev), _t(Ks, dev), _t(Ks, dev),
+                                                render_depth=True, world_points1=_t(np.broadcast_to(pts, (2, h, w, 3)).copy(), dev),
+                                                foreground_masking=True, boundary_mask=_t(np.broadcast_to(bnd[None], (2, h, w)).copy(), dev))
+    torch.cuda.synchronize()
+    fr_o, m_o, d_o, flow_o, _ = wo.forward_warp(np.broadcast_to(img[None], (2, 3, h, w)), np.broadcast_to(rel, (2, 1, h, w)), np.broadcast_to(pts, (2, h, w, 3)),
+                                               w2cs, Ks, render_depth=True, foreground_masking=True, boundary_mask=np.broadcast_to(bnd[None], (2, h, w)),
+                                               ray_triangle_fn=wo.ray_triangle_depth_c)
+    _, m_plain, _, _, _ = wo.forward_warp(np.broadcast_to(img[None], (2, 3, h, w)), np.broadcast_to(rel, (2, 1, h, w)), np.broadcast_to(pts, (2, h, w, 3)), w2cs, Ks)
+    removed = (m_plain != m_o).sum(axis=(1, 2, 3))
+    assert removed[0] > 500 and removed[1] > 500, f"mesh occlusion must actually remove pixels in both items: {removed}"
+    assert int((flow.cpu().numpy() != flow_o).sum()) == 0
+    got_m = m2.cpu().numpy()
+    nd = int((got_m != m_o).sum())
+    print(f"[fg 704x1280] tris {len(tri_z[0])}, behind camera {n_behind}, straddling {n_straddle}; occluded px {removed.tolist()}; mask px differing {nd}")
+    assert nd == 0, f"mask differs on {nd} px"
+    err = np.abs(frame.cpu().numpy() - fr_o)
+    bad = err > (1e-4 + 1e-3 * np.abs(fr_o))
+    assert bad.mean() < 1e-5 and err.max() < 5e-2, (float(bad.mean()), float(err.max()))
+    derr = np.abs(d2.cpu().numpy() - d_o)
+    assert (derr > (1e-4 + 1e-3 * np.abs(d_o))).mean() < 1e-5
+
+
 def test_identity_camera_is_idempotent_on_valid_pixels():
     """Size-independent property: rendering the cache from its own camera returns the source image wherever the mask is 1."""
     from gen3c_amd import renderer

@@ -42,3 +42,24 @@ def test_forward_warp_matches_reference(name, fg):
     assert np.array_equal(m2, z[f"{tag}_mask"]), f"mask differs on {(m2 != z[f'{tag}_mask']).sum()} px"
     np.testing.assert_allclose(frame, z[f"{tag}_frame"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(d2, z[f"{tag}_depth"], rtol=2e-4, atol=2e-5)
+
+
+def test_c_bruteforce_ray_triangle_is_bit_identical_to_the_numpy_restatement():
+    """oracle/c/ray_tri.c (used by the full-resolution mesh-occlusion GPU test) against warp_oracle.ray_triangle_depth on (a) the
+    boundary mesh of the golden scene and (b) random triangles around the camera, incl. behind it / through the origin plane /
+    degenerate (zero-area) ones."""
+    z = _load("warp_mid")
+    h, w = int(z["h"]), int(z["w"])
+    _, cam = warp_oracle.project_points(z["points"][None], z["w2cs"][:1], z["K"][None])
+    pts, m = warp_oracle.downsample_points_mask(cam[0], z["boundary"], 4)
+    tris = warp_oracle.mesh_triangles(pts, m)
+    rays = warp_oracle.camera_rays(h, w, z["K"])
+    assert len(tris) > 50
+    a, b = warp_oracle.ray_triangle_depth(rays, tris), warp_oracle.ray_triangle_depth_c(rays, tris)
+    assert (a > 0).sum() > 100 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rs = np.random.RandomState(4)
+    tr = (rs.standard_normal((300, 3, 3)) * np.array([1.5, 1.5, 2.0]) + np.array([0, 0, 1.0])).astype(np.float32)
+    tr[:10, 2] = tr[:10, 1]  # degenerate
+    tr[10:20, :, 2] = 0.0    # in the camera plane
+    a, b = warp_oracle.ray_triangle_depth(rays[::3, ::3], tr), warp_oracle.ray_triangle_depth_c(rays[::3, ::3], tr)
+    assert (a > 0).mean() > 0.3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
