@@ -7,7 +7,7 @@ intrinsics [F,3,3]):
   * distributed `<dir>/`    - depth.npz['depth'], mask.npz['mask'], camera.npz['w2c','intrinsics'] and the RGB frames as
                               rgb.npz['rgb'] uint8 [F,H,W,3] (this image has no video decoder; rgb.mp4 is read only when
                               OpenCV is importable, as load_data_distributed_format :137-168 does)
-ViPE folders (vipe_utils.py:172-270) need `decord` and are not handled here.
+ViPE folders (vipe_utils.py:172-270) are read by gen3c_amd/vipe_utils.py.
 """
 from __future__ import annotations
 

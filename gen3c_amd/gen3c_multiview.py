@@ -19,6 +19,12 @@ from gen3c_amd.cli_common import Session, add_common_args
 def create_parser() -> argparse.ArgumentParser:
     p = add_common_args(argparse.ArgumentParser(description="GEN3C multi-view key frames -> video on MI355X"))
     p.add_argument("--npz_path", type=str, required=True)
+    # declared by the reference's parser (gen3c_multiview.py:50-85) although the trajectory comes from the npz; accepted, unused there too
+    p.add_argument("--trajectory", type=str, default="left",
+                   choices=["left", "right", "up", "down", "zoom_in", "zoom_out", "clockwise", "counterclockwise", "none"])
+    p.add_argument("--camera_rotation", type=str, default="center_facing", choices=["center_facing", "no_rotation", "trajectory_aligned"])
+    p.add_argument("--movement_distance", type=float, default=0.3)
+    p.add_argument("--noise_aug_strength", type=float, default=0.0)
     return p
 
 
@@ -42,9 +48,17 @@ def demo(args) -> np.ndarray:
 
     video = ses.finalize(ses.run_chunks(images_key[None, 0][:, :, None], render))
     ses.save(video)
+    ses.close()
     return video
 
 
-if __name__ == "__main__":
+def main(argv=None) -> None:
     torch.set_grad_enabled(False)
-    demo(create_parser().parse_args())
+    args = create_parser().parse_args(argv)
+    if args.prompt is None:
+        args.prompt = ""
+    demo(args)
+
+
+if __name__ == "__main__":
+    main()

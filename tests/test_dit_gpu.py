@@ -78,3 +78,39 @@ def test_dit_forward_long_sequence_vs_oracle():
     print(f"[dit 2304 tokens] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
     assert y.shape == y_ref.shape and torch.isfinite(y).all()
     assert rel <= 2e-2 and mx <= 6e-2 * float(y_ref.abs().max())
+
+
+def test_dit_full_width_block_vs_oracle():
+    """Block COMPOSITION at the Cosmos-7B width: D=4096, 32 heads x 128, MLP 16 384, AdaLN-LoRA 256, context 512 x 1024, ONE of the
+    28 blocks + embedder + final layer, on a [16,4,64,64] latent = 4 096 tokens (the slice bench.py's CPU leg times). The kernels are
+    unit-tested at this width elsewhere; this checks their composition (fused QKV slicing, per-head norm + RoPE over 32 heads, gated
+    residuals at ld 4096, 16 384-wide GELU hidden) against the fp32 oracle on the same bf16 weights (~15 s of CPU)."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    from oracle import dit_oracle
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(in_channels=81, rope_t_extrapolation_ratio=2.0, num_blocks=1, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=5)
+    B, T, H, W, M = 1, 4, 64, 64, 512
+    g = torch.Generator().manual_seed(8)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = rnd(B, 16, T, H, W).to(torch.bfloat16)
+    mask = torch.zeros(B, 1, T, H, W, dtype=torch.bfloat16)
+    mask[:, :, :1] = 1
+    pose = (0.5 * rnd(B, 64, T, H, W)).to(torch.bfloat16)
+    ctx = (0.2 * rnd(B, M, 1024)).to(torch.bfloat16)
+    ctx[:, 64:] = 0  # zero-padded T5 tokens stay in the (unmasked) softmax denominator (general_dit.py:407-410)
+    ts = torch.tensor([0.3], dtype=torch.bfloat16)
+    pad = torch.zeros(B, 1, 8 * H, 8 * W, dtype=torch.bfloat16)
+    y = net(x=x.to(dev), timesteps=ts.to(dev), crossattn_emb=ctx.to(dev), crossattn_mask=None, fps=torch.tensor([24.0], device=dev),
+            padding_mask=pad.to(dev), condition_video_indicator=mask[:, :, :, :1, :1].to(dev), condition_video_input_mask=mask.to(dev),
+            condition_video_pose=pose.to(dev))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    y_ref = dit_oracle.dit_forward(sd, x.float(), ts.float(), ctx.float(), mask.float(), pose.float(), pad.float(), torch.tensor([24.0]),
+                                   num_blocks=1, num_heads=32)
+    y = y.float().cpu()
+    rel = float((y - y_ref).norm() / y_ref.norm())
+    mx = float((y - y_ref).abs().max())
+    print(f"[dit D=4096 H=32, 1 block, 4096 tokens] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
+    assert y.shape == y_ref.shape and torch.isfinite(y).all()
+    assert rel <= 1.5e-2 and mx <= 6e-2 * float(y_ref.abs().max())

@@ -23,7 +23,8 @@ def _scene():
     return depth, img, K
 
 
-def test_single_image_chunk_end_to_end():
+def _chain(n_buffers: int, guidance: float, num_steps: int):
+    """Product chain vs the same chain assembled from the CPU oracles. Returns (psnr_db, latent_rel_l2 is folded into psnr only)."""
     from gen3c_amd import renderer
     from gen3c_amd.camera_utils import generate_camera_trajectory
     from gen3c_amd.dit import VideoExtendGeneralDIT
@@ -38,9 +39,20 @@ def test_single_image_chunk_end_to_end():
     # ---- product path
     cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
                                     input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=False, input_format=["B", "C", "H", "W"])
+    sources = [(img, depth, np.eye(4, dtype=np.float32))]
+    if n_buffers == 2:  # a second view pushed like an autoregressive chunk does (cache_3d.py:294-316): it becomes buffer 0 (newest first)
+        ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+        depth2 = (2.5 + 0.006 * xs + 0.008 * ys).astype(np.float32)
+        depth2 = np.where((ys - 40) ** 2 + (xs - 60) ** 2 < 12 ** 2, 1.2 + 0.001 * ys, depth2).astype(np.float32)
+        img2 = np.stack([np.cos(xs * 0.13 - c) * np.sin(ys * 0.21 + c) for c in range(3)], 0).astype(np.float32)
+        w2c2 = np.eye(4, dtype=np.float32)
+        w2c2[0, 3] = -0.25
+        cache.update_cache(t(img2)[None], t(depth2)[None, None], t(w2c2)[None], new_intrinsics=t(K)[None], depth_alignment=False)
+        sources = [(img2, depth2, w2c2)] + sources
     w2cs, Ks = generate_camera_trajectory("left", torch.eye(4, device=dev), t(K), T, 0.3, "center_facing", center_depth=3.0, device=dev)
     renders, masks = cache.render_cache(w2cs, Ks)
-    assert renders.shape == (1, T, 1, 3, H, W) and masks.shape == (1, T, 1, 1, H, W)
+    N = n_buffers
+    assert renders.shape == (1, T, N, 3, H, W) and masks.shape == (1, T, N, 1, H, W)
 
     net = VideoExtendGeneralDIT(max_img_h=48, max_img_w=48, max_frames=16, in_channels=81, model_channels=D, num_blocks=BLOCKS, num_heads=HEADS,
                                 adaln_lora_dim=32, crossattn_emb_channels=CTX, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
@@ -50,29 +62,37 @@ def test_single_image_chunk_end_to_end():
     lat_mean, lat_std = torch.randn(16, 4) * 0.1, torch.rand(16, 4) * 0.5 + 0.75
     tk.register_mean_std(lat_mean, lat_std)
     model = DiffusionGen3CModel(net, tk, latent_shape=(16, 2, H // 8, W // 8))
-    pipe = Gen3cPipeline(model, guidance=1.0, num_steps=3, height=H, width=W, num_video_frames=T, seed=1)
+    pipe = Gen3cPipeline(model, guidance=guidance, num_steps=num_steps, height=H, width=W, num_video_frames=T, seed=1)
     g = torch.Generator().manual_seed(0)
     prompt = (0.2 * torch.randn(1, M, CTX, generator=g)).to(torch.bfloat16)
     prompt[:, M // 2:] = 0
     negp = (0.2 * torch.randn(1, M, CTX, generator=g)).to(torch.bfloat16)
-    model.scheduler.set_timesteps(3)
+    model.scheduler.set_timesteps(num_steps)
     xt = (torch.randn(1, 16, 2, H // 8, W // 8, generator=g) * model.scheduler.init_noise_sigma).to(torch.bfloat16)
     image = t(img)[None, :, None]  # [1,3,1,H,W]
     video = pipe.generate(prompt, image, renders, masks, negative_prompt_embedding=negp, xt=xt.to(dev))
     assert video.shape == (T, H, W, 3) and video.dtype == np.uint8
 
     # ---- the same chain from the CPU oracles (fp32)
-    pts = warp_oracle.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
-    rel = warp_oracle.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    src = []
+    for (im_, dp_, w2c_) in sources:
+        pts = warp_oracle.unproject_points(dp_[None, None], w2c_[None], K[None])
+        rel = warp_oracle.reliable_depth_mask(dp_[None, None], ratio_thresh=0.05).astype(np.float32)
+        src.append((im_, pts[0], rel[0]))
     w2c_np, K_np = w2cs[0].cpu().numpy(), Ks[0].cpu().numpy()
-    fr, mk = [], []
-    for i in range(0, T, 2):  # reference pairing: warp_chunk_size = 2
-        n = min(2, T - i)
-        f_, m_, _, _, _ = warp_oracle.forward_warp(np.broadcast_to(img[None], (n, 3, H, W)), np.broadcast_to(rel, (n, 1, H, W)),
-                                                   np.broadcast_to(pts, (n, H, W, 3)), w2c_np[i:i + n], K_np[i:i + n])
-        fr.append(f_); mk.append(m_)
-    fr, mk = np.concatenate(fr), np.concatenate(mk)
-    assert np.array_equal(masks[0, :, 0].cpu().numpy(), mk), "render masks differ from the oracle"
+    # flattened (B F N) items in reference pairs (warp_chunk_size = 2, cache_3d.py:163-183): N=1 -> two consecutive frames,
+    # N=2 -> both buffers of one frame
+    items = [(f, n) for f in range(T) for n in range(N)]
+    fr = np.zeros((T, N, 3, H, W), np.float32)
+    mk = np.zeros((T, N, 1, H, W), np.float32)
+    for i in range(0, len(items), 2):
+        grp = items[i:i + 2]
+        f_, m_, _, _, _ = warp_oracle.forward_warp(np.stack([src[n][0] for _, n in grp]), np.stack([src[n][2] for _, n in grp]),
+                                                   np.stack([src[n][1] for _, n in grp]), np.stack([w2c_np[f] for f, _ in grp]),
+                                                   np.stack([K_np[f] for f, _ in grp]))
+        for j, (f, n) in enumerate(grp):
+            fr[f, n], mk[f, n] = f_[j], m_[j]
+    assert np.array_equal(masks[0].cpu().numpy(), mk), "render masks differ from the oracle"
     tsd = {k: v.to(torch.bfloat16).float() for k, v in tok_sd.items()}
     mean = lat_mean[:, :2].to(torch.bfloat16).float().reshape(1, 16, 2, 1, 1)
     std = lat_std[:, :2].to(torch.bfloat16).float().reshape(1, 16, 2, 1, 1)
@@ -80,9 +100,14 @@ def test_single_image_chunk_end_to_end():
     bfr = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
     clip = torch.cat([bfr(img)[None, :, None], torch.zeros(1, 3, T - 1, H, W)], dim=2)
     gt = enc(clip).to(torch.bfloat16).float()
-    rv = bfr(fr).permute(1, 0, 2, 3)[None]
-    mv = (bfr(mk) * 2 - 1).repeat(1, 3, 1, 1).permute(1, 0, 2, 3)[None]
-    pose = torch.cat([enc(rv), enc(mv), torch.zeros(1, 32, 2, H // 8, W // 8)], dim=1)
+    lat = []
+    for n in range(N):  # model_gen3c.py:32-57
+        rv = bfr(fr[:, n]).permute(1, 0, 2, 3)[None]
+        mv = (bfr(mk[:, n]) * 2 - 1).repeat(1, 3, 1, 1).permute(1, 0, 2, 3)[None]
+        lat += [enc(rv), enc(mv)]
+    for _ in range(2 - N):
+        lat += [torch.zeros(1, 16, 2, H // 8, W // 8)] * 2
+    pose = torch.cat(lat, dim=1)
     ind = torch.zeros(1, 1, 2, 1, 1); ind[:, :, :1] = 1
     mask_in = ind.expand(1, 1, 2, H // 8, W // 8).contiguous()
     dsd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
@@ -92,16 +117,37 @@ def test_single_image_chunk_end_to_end():
                                                            num_blocks=BLOCKS, num_heads=HEADS)
 
     x = xt.float()
-    for i in range(3):
+    fc, fu = net_fn_factory(prompt.float()), net_fn_factory(negp.float())
+    for i in range(num_steps):
         # cond uses the prompt, uncond the negative prompt AND a zero pose: restate the step with two different contexts
-        fc, fu = net_fn_factory(prompt.float()), net_fn_factory(negp.float())
         x = sampler_oracle.denoise_step(lambda xx, tt, pp: fc(xx, tt, pp) if pp.abs().sum() > 0 else fu(xx, tt, pp),
-                                        x, i, gt, ind, pose, 3, 1.0, 0.001, 1)
+                                        x, i, gt, ind, pose, num_steps, guidance, 0.001, 1)
     y = tok.decode(tsd, x / 0.5, mean, std)
     ref_video = ((1.0 + y).clamp(0, 2) / 2)[0].permute(1, 2, 3, 0).numpy()
 
     got = video.astype(np.float32) / 255.0
     mse = float(((got - ref_video) ** 2).mean())
-    psnr = 10 * np.log10(1.0 / max(mse, 1e-12))
+    return 10 * np.log10(1.0 / max(mse, 1e-12)), mse
+
+
+def test_single_image_chunk_end_to_end():
+    psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=3)
     print(f"[e2e] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
     assert psnr >= 30.0
+
+
+def test_two_buffers_guidance_end_to_end():
+    """N = 2 cache buffers through encode_warped_frames (both (render, mask) latent pairs, no zero padding; reference pairs = both
+    buffers of one target frame) and classifier-free guidance 1.5 (c + g (c - u) with a negative prompt and zeroed pose)."""
+    psnr, mse = _chain(n_buffers=2, guidance=1.5, num_steps=3)
+    print(f"[e2e N=2 g=1.5] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
+    assert psnr >= 33.0  # measured 37.6 dB
+
+
+def test_full_schedule_trajectory_drift():
+    """All 35 steps of the Karras schedule on the tiny model (sigma 80 -> 0.0002, incl. the indicator-off tail and sigma_next = 0):
+    the bf16 HIP trajectory must stay within a stated distance of the fp32 oracle trajectory - drift bound: decoded PSNR >= 33 dB
+    (measured 37.4 dB, the same as after 3 steps: 37.5 dB - no accumulation over the schedule)."""
+    psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=35)
+    print(f"[e2e 35 steps] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
+    assert psnr >= 33.0
