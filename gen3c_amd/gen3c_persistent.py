@@ -6,7 +6,8 @@ server keeps per GPU worker. Models are built once; `seed_model_from_values` bui
 Differences, all because the models around the path are inputs here: there is no MoGe, so seeding from a single
 image REQUIRES `depths_np` (the reference instead refuses it and predicts depth), and the per-chunk depth of autoregressive
 single-image requests comes from `depth_estimator` (callable image[3,H,W] in [0,1] -> (depth[1,1,H,W], mask)) or, by default,
-from the cache's own rendering; the text prompt is a T5 embedding file in `args`; the video is written as .npz."""
+from the cache's own rendering; the text prompt follows cli_common.TextEmbedder
+(embedding file, T5 checkpoint, or dummy zeros); the video is written as .mp4 when an encoder is importable, else .npz."""
 from __future__ import annotations
 
 import argparse
@@ -158,7 +159,7 @@ class Gen3cPersistentModel:
         video_b = video.transpose(0, 3, 1, 2)[None]  # [1, n_frames, C, H, W] (:497)
         return {"rendered_warp_images": renders, "video": video_b, "rendered_warp_images_no_overlap": renders, "video_no_overlap": video_b,
                 "predicted_depth": np.concatenate(depths, axis=0) if return_estimated_depths else None,
-                "video_save_path": os.path.join(self.args.video_save_folder, name + ".npz")}
+                "video_save_path": getattr(ses, "saved_path", os.path.join(self.args.video_save_folder, name + ".npz"))}
 
     # ---- helpers (gen3c_persistent.py:518-569)
     def prepare_camera_for_inference(self, view_cameras, view_camera_intrinsics, old_size, new_size):
