@@ -212,3 +212,84 @@ def test_cli_loads_checkpoint_layout(tmp_path):
     print(f"[checkpoint cli] same checkpoint twice: mean |diff| {d12:.3f}; checkpoint vs random init: {d13:.3f}")
     # same checkpoint and seed -> the same video up to the splat's atomic summation order; other weights -> another video
     assert d12 < 0.5 and d13 > 10 * max(d12, 0.05)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# rows f2 / f3 / f4 against the REFERENCE's own Python (tests/golden/cache_rows_f.npz, tools/gen_golden_cache.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _gold():
+    from tests.golden_io import GOLD
+    return np.load(GOLD / "cache_rows_f.npz")
+
+
+def _close_pixels(got, ref, what):
+    err = np.abs(got - ref)
+    bad = err > (1e-4 + 1e-3 * np.abs(ref))
+    assert bad.mean() < 1e-4 and err.max() < 5e-2, f"{what}: {int(bad.sum())} px off, max {err.max():.3e}"
+
+
+@pytest.mark.parametrize("tag,kw", [("top2", dict(frame_buffer_max=2)), ("top2_nomax", dict(frame_buffer_max=2, mask_for_max_buffer_model=False)),
+                                    ("thr70", dict(frame_buffer_max=2, mask_full_threshold=0.7)), ("all", dict(frame_buffer_max=4))])
+def test_buffer_selector_matches_reference(tag, kw):
+    """Cache3D_BufferSelector.render_cache (cache_3d.py:346-421): top-K buffers by mask overlap and the near-full exclusivity mask
+    (thr70: frame 0 keeps buffer 0, middle frames keep buffer 1, late frames keep both). Masks - hence the selection - bit-exact."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    z = _gold()
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    c = renderer.Cache3D_BufferSelector(input_image=t("sel_images")[None], input_depth=t("sel_depth")[None], input_mask=t("sel_mask")[None],
+                                        input_w2c=t("sel_w2c")[None], input_intrinsics=t("sel_K")[None], filter_points_threshold=0.05,
+                                        input_format=["B", "N", "C", "H", "W"], foreground_masking=False, **kw)
+    px, mk = c.render_cache(t("sel_tw2c")[None], t("sel_tK")[None])
+    ref_m = z[f"sel:{tag}:masks"]
+    assert tuple(mk.shape) == ref_m.shape
+    nd = int((mk.cpu().numpy() != ref_m).sum())
+    assert nd == 0, f"{tag}: {nd} mask px differ from the reference"
+    if f"sel:{tag}:pixels" in z.files:
+        _close_pixels(px.cpu().numpy(), z[f"sel:{tag}:pixels"], tag)
+    if tag == "thr70":  # the case really exercises all three branches of the exclusivity logic
+        per = ref_m.mean(axis=(3, 4, 5))[0]
+        assert (per[:, 1] == 0).any() and (per[:, 0] == 0).any() and ((per[:, 0] > 0) & (per[:, 1] > 0)).any()
+    if tag == "all":
+        d, dm = c.render_cache(t("sel_tw2c")[None], t("sel_tK")[None], render_depth=True)
+        assert np.array_equal(dm.cpu().numpy(), z["sel:all:depth_masks"])
+        _close_pixels(d.cpu().numpy(), z["sel:all:depth"], "depth")
+
+
+@pytest.mark.parametrize("start", [0, 4])
+def test_cache4d_windows_match_reference(start):
+    """Cache4D.render_cache(start_frame_idx) (cache_3d.py:151-236, 424-433): target frame f is rendered from source frame start + f."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    z = _gold()
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    c = renderer.Cache4D(input_image=t("c4_images").clone(), input_depth=t("c4_depth"), input_mask=t("c4_mask"), input_w2c=t("c4_w2c"),
+                         input_intrinsics=t("c4_K"), filter_points_threshold=0.05, input_format=["F", "C", "H", "W"], foreground_masking=False)
+    px, mk = c.render_cache(t("c4_tw2c")[start:start + 5][None], t("c4_K")[start:start + 5][None], start_frame_idx=start)
+    assert np.array_equal(mk.cpu().numpy(), z[f"c4:{start}:masks"])
+    _close_pixels(px.cpu().numpy(), z[f"c4:{start}:pixels"], f"window {start}")
+
+
+def test_persistent_model_seeding_and_cameras_match_reference(tmp_path):
+    """Gen3cPersistentModel.seed_model_from_values (multi-frame branch, gen3c_persistent.py:203-268), prepare_camera_for_inference
+    (:518-536) and resize_intrinsics (:35-52) against the reference's own functions."""
+    from gen3c_amd import gen3c_persistent as gp
+    z = _gold()
+    PH, PW = (int(v) for v in z["seed_hw"])
+    args = gp.create_parser().parse_args(["--height", str(PH), "--width", str(PW), "--num_steps", "2", "--random_init", "--tiny",
+                                          "--video_save_folder", str(tmp_path), "--video_save_name", "p"])
+    m = gp.Gen3cPersistentModel(args)
+    ret = m.seed_model_from_values(z["seed_images01"], z["seed_depths"], z["seed_w2c"], z["seed_focal"], z["seed_pp_rel"], z["seed_res"],
+                                   masks_np=z["seed_masks"])
+    for got, key in zip(ret, ("seed_ret_w2c", "seed_ret_focal", "seed_ret_pp", "seed_ret_res")):
+        np.testing.assert_array_equal(np.asarray(got), z[key])
+    np.testing.assert_allclose(m.seeding_image.cpu().numpy(), z["seed_seeding_image"], rtol=0, atol=2e-6)  # bicubic-antialias resize
+    np.testing.assert_allclose(m.cache.input_points.cpu().numpy(), z["seed_cache_points"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(m.cache.input_mask.cpu().numpy(), z["seed_cache_mask"])
+    np.testing.assert_array_equal(m.cache.input_image.cpu().numpy(), z["seed_cache_image"])
+    H0, W0 = z["c4_images"].shape[-2:]
+    cams, intr = m.prepare_camera_for_inference(z["c4_tw2c"][:5], z["c4_K"][:5], (H0, W0), (PH, PW))
+    np.testing.assert_array_equal(cams.cpu().numpy(), z["pc_w2c"])
+    np.testing.assert_array_equal(intr.cpu().numpy(), z["pc_K"])
+    np.testing.assert_array_equal(gp.resize_intrinsics(z["ri_in"], (H0, W0), (96, 160)), z["ri_plain"])
+    np.testing.assert_array_equal(gp.resize_intrinsics(torch.from_numpy(z["ri_in"]), (H0, W0), (90, 160), crop_size=(88, 152)).numpy(), z["ri_crop"])
