@@ -181,8 +181,10 @@ class Session:
             sd = sd.get("model", sd)
             net.load_state_dict({k[len("net."):]: v for k, v in sd.items() if k.startswith("net.")}, strict=True)
             tk.load_weights(os.path.join(args.checkpoint_dir, getattr(args, "tokenizer_dir", "Cosmos-Tokenize1-CV8x8x8-720p")))
+        self.cp_group = None  # also shards the renderer's item pairs and the tokenizer encodes of a chunk
         if args.num_gpus > 1:
-            net.enable_context_parallel(parallel_state.get_context_parallel_group())
+            self.cp_group = parallel_state.get_context_parallel_group()
+            net.enable_context_parallel(self.cp_group)
         self.net, self.tokenizer = net, tk
         self.model = DiffusionGen3CModel(net, tk, latent_shape=(16, tk.get_latent_num_frames(self.chunk), H // 8, W // 8))
         self.pipe = Gen3cPipeline(self.model, guidance=args.guidance, num_steps=args.num_steps, height=H, width=W, fps=args.fps,

@@ -37,6 +37,7 @@ def generate_one(ses: Session, args, source) -> np.ndarray:
     cache = renderer.Cache4D(input_image=image.clone(), input_depth=depth, input_mask=mask, input_w2c=w2c, input_intrinsics=K,
                              filter_points_threshold=args.filter_points_threshold, input_format=["F", "C", "H", "W"],
                              foreground_masking=args.foreground_masking)
+    cache.shard_group = ses.cp_group  # multi-GPU: every rank renders its share of the item pairs
     w2cs, Ks = generate_camera_trajectory(args.trajectory, w2c[0], K[0], args.num_video_frames, args.movement_distance, args.camera_rotation,
                                           center_depth=1.0, device=dev)
     ses.rendered_warps.clear()

@@ -39,6 +39,7 @@ def demo(args) -> np.ndarray:
     cache = renderer.Cache3D_BufferSelector(frame_buffer_max=2, input_image=images_key[None], input_depth=depth_key[None], input_mask=mask_key[None],
                                             input_w2c=w2c_key[None], input_intrinsics=K_key[None], filter_points_threshold=args.filter_points_threshold,
                                             input_format=["B", "N", "C", "H", "W"], foreground_masking=args.foreground_masking)
+    cache.shard_group = ses.cp_group  # multi-GPU: every rank renders its share of the item pairs
     w2cs = t("w2cs_all")[: args.num_video_frames][None]
     assert w2cs.shape[1] == args.num_video_frames, f"w2cs_all holds {w2cs.shape[1]} poses, --num_video_frames {args.num_video_frames}"
     Ks = t("Ks_all")[: args.num_video_frames][None] if "Ks_all" in npz.files else K_key[-1][None, None].repeat(1, w2cs.shape[1], 1, 1)

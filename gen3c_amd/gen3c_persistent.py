@@ -88,6 +88,7 @@ class Gen3cPersistentModel:
             self.cache = renderer.Cache4D(input_image=image.clone(), input_depth=depth, input_mask=mask, input_w2c=w2c, input_intrinsics=Kt,
                                           input_format=["F", "C", "H", "W"], **common)
             seeding = image
+        self.cache.shard_group = self.session.cp_group  # multi-GPU: render item pairs are split over the ranks
         if seeding.shape[2] != self.H or seeding.shape[3] != self.W:
             seeding = torch.nn.functional.interpolate(seeding, size=(self.H, self.W), mode="bicubic", antialias=True, align_corners=False)
         self.seeding_image = seeding[:, :, None]

@@ -159,6 +159,7 @@ def generate_one(ses: Session, args, image_path: str, depth_path, moge_model) ->
                                     generator=torch.Generator(device=dev).manual_seed(args.seed), input_image=image, input_depth=depth,
                                     input_w2c=w2c0[None], input_intrinsics=K[None], filter_points_threshold=args.filter_points_threshold,
                                     foreground_masking=args.foreground_masking, input_format=["B", "C", "H", "W"])
+    cache.shard_group = ses.cp_group  # multi-GPU: every rank renders its share of the item pairs
     center_depth = 1.0  # the reference passes this constant (gen3c_single_image.py:340-349)
     traj = "left" if args.trajectory == "none" else args.trajectory
     dist_ = 0.0 if args.trajectory == "none" else args.movement_distance

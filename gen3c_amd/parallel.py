@@ -133,6 +133,49 @@ def init_distributed(backend: Optional[str] = None) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# sharding the replicated stages of a chunk: render items and tokenizer encodes are independent units
+# ------------------------------------------------------------------------------------------------------------------
+def shard_range(n_units: int, rank: int, world: int):
+    """Contiguous, balanced split of `n_units` over `world` ranks -> [lo, hi) of `rank` (the first n % world ranks get one more)."""
+    q, r = divmod(n_units, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_rows(local: torch.Tensor, counts: List[int], group) -> torch.Tensor:
+    """All-gather of per-rank row blocks of different lengths (`counts[r]` rows on rank r, identical trailing shape): every rank pads
+    its block to max(counts), one all_gather_into_tensor, the padding is cut out. Rank-major = the original unit order."""
+    world = dist.get_world_size(group)
+    assert len(counts) == world and local.shape[0] == counts[dist.get_rank(group)]
+    m = max(counts)
+    pad = local if local.shape[0] == m else torch.cat([local, local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))], 0)
+    full = torch.empty((world * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, pad.contiguous(), group=group)
+    if all(c == m for c in counts):
+        return full
+    return torch.cat([full[r * m:r * m + c] for r, c in enumerate(counts)], 0)
+
+
+def run_jobs_round_robin(jobs: List[Callable[[], torch.Tensor]], group, shape, dtype, device) -> List[torch.Tensor]:
+    """Independent jobs whose results all have `shape` / `dtype` (the 2N+1 tokenizer encodes of a chunk): job j runs on rank
+    j % world only, the results are all-gathered and returned in job order on every rank. group=None (or one rank): plain sequential
+    execution. A rank without a job (more ranks than jobs) contributes zeros that nobody reads."""
+    world = 1 if group is None else dist.get_world_size(group)
+    if world == 1:
+        return [j() for j in jobs]
+    rank = dist.get_rank(group)
+    slots = (len(jobs) + world - 1) // world
+    local = torch.zeros((slots, *shape), dtype=dtype, device=device)
+    for i, j in enumerate(range(rank, len(jobs), world)):
+        out = jobs[j]()
+        assert tuple(out.shape) == tuple(shape) and out.dtype == dtype, f"job {j}: {tuple(out.shape)} {out.dtype} vs declared {tuple(shape)} {dtype}"
+        local[i] = out
+    full = torch.empty((world * slots, *shape), dtype=dtype, device=device)
+    dist.all_gather_into_tensor(full, local, group=group)
+    return [full[(j % world) * slots + j // world] for j in range(len(jobs))]
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # context-parallel self-attention
 # ------------------------------------------------------------------------------------------------------------------
 def _default_backend():

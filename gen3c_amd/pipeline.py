@@ -97,12 +97,21 @@ class DiffusionGen3CModel:
         zero-pad to frame_buffer_max buffers; concat on channels -> [B, 32*frame_buffer_max, T_lat, h, w]."""
         assert condition_state.dim() == 6
         mask = (condition_state_mask * 2 - 1).repeat(1, 1, 1, 3, 1, 1)
-        latents = []
-        for i in range(condition_state.shape[2]):
-            vid = self.encode(condition_state[:, :, i].permute(0, 2, 1, 3, 4).to(dtype)).contiguous()
-            msk = self.encode(mask[:, :, i].permute(0, 2, 1, 3, 4).to(dtype)).contiguous()
-            latents += [vid, msk]
-        for _ in range(self.frame_buffer_max - condition_state.shape[2]):
+        n_buf = condition_state.shape[2]
+        jobs = []
+        for i in range(n_buf):
+            jobs.append(lambda i=i: self.encode(condition_state[:, :, i].permute(0, 2, 1, 3, 4).to(dtype)).contiguous())
+            jobs.append(lambda i=i: self.encode(mask[:, :, i].permute(0, 2, 1, 3, 4).to(dtype)).contiguous())
+        # Multi-GPU (SURVEY.md 8e): the 2N encodes are independent clips - with context parallelism on, clip j is encoded by rank
+        # j % cp only and the 7.2 MB latents are all-gathered (the reference encodes all of them on every rank).
+        group = self.net.cp_group if self.net.is_context_parallel_enabled else None
+        B, T = condition_state.shape[:2]
+        tk = self.tokenizer
+        shape = (B, tk.channel, tk.get_latent_num_frames(T), condition_state.shape[-2] // tk.spatial_compression_factor,
+                 condition_state.shape[-1] // tk.spatial_compression_factor)
+        from .parallel import run_jobs_round_robin
+        latents = run_jobs_round_robin(jobs, group, shape, dtype, condition_state.device)
+        for _ in range(self.frame_buffer_max - n_buf):
             latents += [torch.zeros_like(latents[0]), torch.zeros_like(latents[1])]
         return torch.cat(latents, dim=1)
 

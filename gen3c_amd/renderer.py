@@ -190,6 +190,7 @@ class Cache3D_Base:
             dm = reliable_depth_mask_range_batch(input_depth.reshape(-1, 1, H, W), ratio_thresh=self.filter_points_threshold)
             dm = dm.reshape(B, F, N, V, 1, H, W).to(f32)
             self.input_mask = dm if self.input_mask is None else self.input_mask * dm
+        self.shard_group = None  # torch.distributed group over which render_cache splits its item pairs (None: render everything here)
         self.boundary_mask = None
         if foreground_masking:
             dm = reliable_depth_mask_range_batch(input_depth.reshape(-1, 1, H, W))
@@ -218,9 +219,21 @@ class Cache3D_Base:
         Ks = target_intrinsics.to(self.device, f32).reshape(B, Ft, 1, 3, 3).expand(B, Ft, N, 3, 3).reshape(-1, 3, 3)
         n = imgs.shape[0]
         step = max(2, items_per_launch // 2 * 2)  # never split a reference pair
+        # Multi-GPU: the items are independent EXCEPT that bilinear_splatting normalises its depth weights by the
+        # maximum over the 2 items of one reference call - so the unit that is sharded over the ranks of `shard_group` is the PAIR
+        # (2j, 2j+1) of the flattened (B F N) axis; every rank renders a contiguous run of pairs and the results are all-gathered.
+        group = getattr(self, "shard_group", None)
+        lo, hi, counts = 0, n, None
+        if group is not None and torch.distributed.get_world_size(group) > 1:
+            from .parallel import shard_range
+            world, rank = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+            n_pairs = (n + 1) // 2
+            ranges = [shard_range(n_pairs, r, world) for r in range(world)]
+            counts = [min(2 * b, n) - min(2 * a, n) for a, b in ranges]
+            lo, hi = min(2 * ranges[rank][0], n), min(2 * ranges[rank][1], n)
         frames, masks, depths = [], [], []
-        for i in range(0, n, step):
-            s = slice(i, min(i + step, n))
+        for i in range(lo, hi, step):
+            s = slice(i, min(i + step, hi))
             fr, mk, dp, _ = forward_warp(imgs[s], None if msk is None else msk[s], None, None, w2cs[s], Ks[s], Ks[s],
                                          render_depth=render_depth, world_points1=pts[s],
                                          foreground_masking=self.foreground_masking,
@@ -229,10 +242,18 @@ class Cache3D_Base:
             masks.append(mk)
             if render_depth:
                 depths.append(dp)
-        masks = torch.cat(masks).reshape(bs, Ft, N, 1, H, W)
+
+        def collect(parts, tail):
+            local = torch.cat(parts) if parts else torch.empty((0, *tail), dtype=f32, device=self.device)
+            if counts is None:
+                return local
+            from .parallel import gather_rows
+            return gather_rows(local, counts, group)
+
+        masks = collect(masks, (1, H, W)).reshape(bs, Ft, N, 1, H, W)
         if render_depth:
-            return torch.cat(depths).reshape(bs, Ft, N, H, W), masks
-        return torch.cat(frames).reshape(bs, Ft, N, 3, H, W), masks
+            return collect(depths, (H, W)).reshape(bs, Ft, N, H, W), masks
+        return collect(frames, (3, H, W)).reshape(bs, Ft, N, 3, H, W), masks
 
 
 class Cache3D_Buffer(Cache3D_Base):

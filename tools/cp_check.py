@@ -1,7 +1,8 @@
 """Context-parallel end-to-end check with the REAL HIP kernels on ONE GPU: N ranks (torchrun) share cuda:0 and talk over
 gloo (RCCL refuses several ranks on one device); each rank compares the CP denoise step on its frame shard against
 the same step computed without CP on the full latent. Exercises dit.enable_context_parallel, table slicing,
-ContextParallelAttention (all-gather-KV in head groups) and the sampler's CP splits exactly as bench.py --gpus N does.
+ContextParallelAttention (all-gather-KV in head groups) and the sampler's CP splits exactly as bench.py --gpus N does, then the
+sharded render pairs / tokenizer encodes of a chunk (bit-identical to the replicated computation).
 
   torchrun --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/cp_check.py
 """
@@ -52,7 +53,51 @@ def main():
     rel = float((part.float() - ref).norm() / ref.norm())
     mx = float((part.float() - ref).abs().max())
     print(f"[cp_check] rank {rank}/{world}: CP vs non-CP denoise step rel_l2={rel:.3e} max_abs={mx:.3e}", flush=True)
-    ok = torch.tensor([1.0 if (rel < 5e-3 and np.isfinite(rel)) else 0.0], device=dev if backend == "nccl" else "cpu")
+    good = rel < 5e-3 and np.isfinite(rel)
+
+    # ---- the chunk's other stages, sharded over the same group: render item pairs and tokenizer encodes with the real
+    # kernels must be bit-identical to the replicated computation on every rank
+    from gen3c_amd import renderer
+    from gen3c_amd.pipeline import DiffusionGen3CModel
+    from gen3c_amd.tokenizer import VideoTokenizer
+    group = net.cp_group
+    hh, ww, n_frames = 64, 96, 9
+    ys, xs = np.mgrid[0:hh, 0:ww].astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    K = t(np.array([[80.0, 0, ww / 2], [0, 80.0, hh / 2], [0, 0, 1]], np.float32))
+    for n_buf, fg in ((1, False), (2, True)):
+        depth = (3.0 + 0.01 * xs + 0.004 * ys).astype(np.float32)
+        depth = np.where((ys - 30) ** 2 + (xs - 40) ** 2 < 15 ** 2, 1.5 + 0.002 * xs, depth).astype(np.float32)
+        img = np.stack([np.sin(xs * 0.2 + c) * np.cos(ys * 0.15 - c) for c in range(3)], 0).astype(np.float32)
+        cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                        input_intrinsics=K[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
+        if n_buf == 2:
+            w2 = torch.eye(4, device=dev)
+            w2[0, 3] = -0.2
+            cache.update_cache(t(img[::-1].copy())[None], t(depth * 1.1)[None, None], w2[None], new_intrinsics=K[None], depth_alignment=False)
+        w2cs = torch.eye(4, device=dev).repeat(1, n_frames, 1, 1)
+        w2cs[0, :, 0, 3] = torch.linspace(0.0, 0.3, n_frames, device=dev)
+        Ks = K.repeat(1, n_frames, 1, 1)
+        full_r = cache.render_cache(w2cs, Ks)
+        cache.shard_group = group
+        shard_r = cache.render_cache(w2cs, Ks)
+        same = all(torch.equal(a, b) for a, b in zip(full_r, shard_r))
+        print(f"[cp_check] rank {rank}: sharded render (N={n_buf}, foreground_masking={fg}) == replicated: {same}", flush=True)
+        good = good and same
+    tk = VideoTokenizer(pixel_chunk_duration=n_frames, channels=16, device=dev)
+    tk.net.init_random(seed=2)
+    tk.register_mean_std(torch.zeros(16, 32), torch.ones(16, 32))
+    model = DiffusionGen3CModel(net, tk, latent_shape=(16, 2, hh // 8, ww // 8))
+    renders, masks = shard_r
+    net.disable_context_parallel()
+    lat_full = model.encode_warped_frames(renders, masks, torch.bfloat16)
+    net.enable_context_parallel(group)
+    lat_shard = model.encode_warped_frames(renders, masks, torch.bfloat16)
+    same = torch.equal(lat_full, lat_shard) and lat_full.shape == (1, 64, 2, hh // 8, ww // 8)
+    print(f"[cp_check] rank {rank}: sharded tokenizer encodes (4 clips over {world} ranks) == replicated: {same}", flush=True)
+    good = good and same
+    torch.cuda.synchronize()
+    ok = torch.tensor([1.0 if good else 0.0], device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     if ok.item() != 1.0:
