@@ -14,17 +14,36 @@ namespace {
 constexpr int LN_THREADS = 256;
 constexpr int LN_MAX_CHUNKS = 4;  // D <= 256*8*4 = 8192
 
-__global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+// POS: first x[row] += pos_emb(row) IN PLACE ("x = x + extra_per_block_pos_emb" at the top of every block, blocks.py:547-548), then the
+// LayerNorm of the updated row - one pass over x instead of two, and the [S*B, D] embedding table is never materialised: it is rebuilt
+// per row from the three per-axis tables with the reference's bf16 rounding points (position_embedding.py:218-233 + normalize,
+// attention.py:108-124):  e = bf16( bf16( bf16(pe_t[t] + pe_h[h]) + pe_w[w] ) / norm[s] ),  x = bf16(x + e),
+// norm[s] = bf16(1e-6 + ||pe_t[t]+pe_h[h]+pe_w[w]||_2 / sqrt(D)) precomputed per token; rows are (s, b), b fastest, s = (t*Hp + h)*Wp + w.
+struct PosEmbArgs {
+    const bf16_t* pe_t; const bf16_t* pe_h; const bf16_t* pe_w; const bf16_t* norm;
+    int Hp, Wp, B;
+};
+
+template <bool POS>
+__global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restrict__ x, int64_t ldx,
                                                                  const bf16_t* __restrict__ shift,
                                                                  const bf16_t* __restrict__ scale, int64_t ldmod,
                                                                  int mod_rows, bf16_t* __restrict__ out, int64_t ldo,
-                                                                 int rows, int D, float eps) {
+                                                                 int rows, int D, float eps, PosEmbArgs pe) {
     __shared__ float red[2][LN_THREADS / 64];
     const int row = blockIdx.x;
     if (row >= rows) return;
     const int tid = threadIdx.x;
     const int nchunk = D >> 3;
-    const bf16_t* xr = x + (int64_t)row * ldx;
+    bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t *pt = nullptr, *ph = nullptr, *pw = nullptr;
+    float pnorm = 1.f;
+    if (POS) {
+        const int sidx = row / pe.B;
+        const int wq = sidx % pe.Wp, hq = (sidx / pe.Wp) % pe.Hp, tq = sidx / (pe.Wp * pe.Hp);
+        pt = pe.pe_t + (int64_t)tq * D; ph = pe.pe_h + (int64_t)hq * D; pw = pe.pe_w + (int64_t)wq * D;
+        pnorm = (float)pe.norm[sidx];
+    }
 
     float v[LN_MAX_CHUNKS][8];
     float s = 0.f;
@@ -32,7 +51,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(const bf16_t* _
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
         const int ch = tid + c * LN_THREADS;
         if (ch < nchunk) {
-            const bf16x8 t = load_bf16x8(xr + ch * 8);
+            bf16x8 t = load_bf16x8(xr + ch * 8);
+            if (POS) {
+                const bf16x8 a = load_bf16x8(pt + ch * 8), b = load_bf16x8(ph + ch * 8), cw = load_bf16x8(pw + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16_t t1 = f32_to_bf16((float)a[e] + (float)b[e]);
+                    const bf16_t t2 = f32_to_bf16((float)t1 + (float)cw[e]);
+                    const bf16_t em = f32_to_bf16((float)t2 / pnorm);
+                    t[e] = f32_to_bf16((float)t[e] + (float)em);
+                }
+                store_bf16x8(xr + ch * 8, t);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
         } else {
@@ -276,9 +306,28 @@ extern "C" int g3_layernorm_modulate_bf16(const void* x, int64_t ldx, const void
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: D=%d must be a multiple of 8 and <= %d", D, LN_THREADS * 8 * LN_MAX_CHUNKS);
     if ((ldx & 7) || (ldo & 7) || (ldmod & 7) || mod_rows <= 0)
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: leading dims must be multiples of 8");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps);
+    hipLaunchKernelGGL(ln_modulate_kernel<false>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
+                       (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, PosEmbArgs{});
     return g3_check_launch("g3_layernorm_modulate_bf16");
+}
+
+extern "C" int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const void* pe_t, const void* pe_h, const void* pe_w,
+                                                 const void* pos_norm, int T, int Hp, int Wp, int B, const void* shift,
+                                                 const void* scale, int64_t ldmod, int mod_rows, void* out, int64_t ldo, int D,
+                                                 float eps, void* stream) {
+    if (!x || !pe_t || !pe_h || !pe_w || !pos_norm || !shift || !scale || !out)
+        return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: null operand");
+    if (T <= 0 || Hp <= 0 || Wp <= 0 || B <= 0 || D <= 0 || (D & 7) || D > LN_THREADS * 8 * LN_MAX_CHUNKS)
+        return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: bad shape (T=%d Hp=%d Wp=%d B=%d D=%d)", T, Hp, Wp, B, D);
+    if ((ldx & 7) || (ldo & 7) || (ldmod & 7) || mod_rows <= 0)
+        return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: leading dims must be multiples of 8");
+    const int64_t rows64 = (int64_t)T * Hp * Wp * B;
+    if (rows64 > 0x7fffffff) return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: too many rows");
+    const int rows = (int)rows64;
+    PosEmbArgs pe{(const bf16_t*)pe_t, (const bf16_t*)pe_h, (const bf16_t*)pe_w, (const bf16_t*)pos_norm, Hp, Wp, B};
+    hipLaunchKernelGGL(ln_modulate_kernel<true>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                       (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, pe);
+    return g3_check_launch("g3_posemb_layernorm_modulate_bf16");
 }
 
 extern "C" int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, const float* cos_table,

@@ -319,17 +319,26 @@ class VideoExtendGeneralDIT(nn.Module):
         freqs = freqs[rank * T:(rank + 1) * T].reshape(T * Hp * Wp, 128).float()
         cos, sin = torch.cos(freqs).contiguous(), torch.sin(freqs).contiguous()
 
-        pe_t = self.extra_pos_embedder.pos_emb_t[:Tg][rank * T:(rank + 1) * T]
-        pe_h = self.extra_pos_embedder.pos_emb_h[:Hp]
-        pe_w = self.extra_pos_embedder.pos_emb_w[:Wp]
+        # absolute position embedding: only the per-token normaliser is precomputed (bf16, [S]); the embedding itself is rebuilt from
+        # the three per-axis tables inside the fused kernel (g3_posemb_layernorm_modulate_bf16), with the same bf16 rounding points as here
+        pe_t = self.extra_pos_embedder.pos_emb_t[:Tg][rank * T:(rank + 1) * T].contiguous()
+        pe_h = self.extra_pos_embedder.pos_emb_h[:Hp].contiguous()
+        pe_w = self.extra_pos_embedder.pos_emb_w[:Wp].contiguous()
         emb = (pe_t[:, None, None, :] + pe_h[None, :, None, :]) + pe_w[None, None, :, :]  # bf16 adds, reference order
         norm = torch.linalg.vector_norm(emb, dim=-1, keepdim=True, dtype=torch.float32)
         norm = torch.add(1e-6, norm, alpha=math.sqrt(1.0 / emb.shape[-1]))
-        emb = emb / norm.to(emb.dtype)
-        D = emb.shape[-1]
-        emb = emb.reshape(T * Hp * Wp, 1, D).expand(-1, B, -1).reshape(T * Hp * Wp * B, D).contiguous()
-        self._tables[key] = (cos, sin, emb)
+        pos = dict(pe_t=pe_t, pe_h=pe_h, pe_w=pe_w, norm=norm.to(emb.dtype).reshape(T * Hp * Wp).contiguous())
+        del emb
+        self._tables[key] = (cos, sin, pos)
         return self._tables[key]
+
+    def position_embedding_rows(self, B: int, T: int, Hp: int, Wp: int, fps, device) -> torch.Tensor:
+        """The materialised [S*B, D] per-block absolute position embedding (tests / debugging; the forward pass never builds it)."""
+        pos = self._position_tables(B, T, Hp, Wp, fps, device)[2]
+        emb = (pos["pe_t"][:, None, None, :] + pos["pe_h"][None, :, None, :]) + pos["pe_w"][None, None, :, :]
+        emb = emb / pos["norm"].reshape(T, Hp, Wp, 1)
+        D = emb.shape[-1]
+        return emb.reshape(T * Hp * Wp, 1, D).expand(-1, B, -1).reshape(T * Hp * Wp * B, D).contiguous()
 
     # ------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -384,7 +393,7 @@ class VideoExtendGeneralDIT(nn.Module):
 
         pk = self._pack()
         P = pk["P"]
-        cos, sin, pos_emb = self._position_tables(B, Tp, Hp, Wp, fps, dev)
+        cos, sin, pos = self._position_tables(B, Tp, Hp, Wp, fps, dev)
 
         xs = ops.gemm_nt(patches, P["x_embedder.proj.1.weight"])  # [S*B, D]
 
@@ -398,14 +407,12 @@ class VideoExtendGeneralDIT(nn.Module):
 
         # ---- context
         M = crossattn_emb.shape[1]
-        ctx = crossattn_emb.to(torch.bfloat16).permute(1, 0, 2).reshape(M * B, -1).contiguous()  # rows (m, b)
-
         nH = self.num_heads
-        for blk in pk["blocks"]:
-            ops.add_inplace(xs, pos_emb)
-            # -- self attention
+        ca_kv = self._cross_attention_kv(pk, crossattn_emb)
+        for bi, blk in enumerate(pk["blocks"]):
+            # -- self attention; "x = x + extra_per_block_pos_emb" (blocks.py:547-548) rides in the same pass over x as the LayerNorm
             shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
-            h = ops.layernorm_modulate(xs, shift, scale)
+            h = ops.posemb_layernorm_modulate(xs, pos["pe_t"], pos["pe_h"], pos["pe_w"], pos["norm"], Tp, Hp, Wp, B, shift, scale)
             if self._cp_attn is not None:
                 # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
                 # every output element sees the same K order, so this is bit-identical to the single fused GEMM)
@@ -427,9 +434,7 @@ class VideoExtendGeneralDIT(nn.Module):
             h = ops.layernorm_modulate(xs, shift, scale)
             q = ops.gemm_nt(h, blk["ca_q"])
             q = ops.qk_rmsnorm_rope(q, blk["ca_qn"], None, None, S, B, nH)
-            kv = ops.gemm_nt(ctx, blk["ca_kv"])  # [M*B, 2D]
-            k = ops.qk_rmsnorm_rope(kv[:, :D], blk["ca_kn"], None, None, M, B, nH)
-            vt = ops.transpose_v(kv[:, D:], M, B, nH)
+            k, vt = ca_kv[bi]
             o = ops.flash_attn(q, k, vt, S, M, B, nH)
             ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- MLP
@@ -444,6 +449,29 @@ class VideoExtendGeneralDIT(nn.Module):
         h = ops.layernorm_modulate(xs, shift, scale)
         y = ops.gemm_nt(h, P["final_layer.linear.weight"])  # [S*B, p1*p2*t*C]
         return ops.dit_unpatchify(y, B, self.out_channels, T, H, W, pt, ps)
+
+    def _cross_attention_kv(self, pk, crossattn_emb: torch.Tensor):
+        """Per block: K = RMSNorm(to_k(context)) and V^T of the cross-attention (attention.py:247-280 with the T5 context as k/v
+        input). They depend on the weights and the context only - not on x or the timestep - so they are computed once per
+        (weight set, context tensor) and reused by the 2 x 35 forwards of a chunk (28 x 2 x 4.3 MB per context). The cache key is
+        the context tensor's storage address + in-place version counter + shape / dtype; a new prompt tensor or an in-place edit
+        rebuilds the entry."""
+        key = (crossattn_emb.data_ptr(), crossattn_emb._version, tuple(crossattn_emb.shape), crossattn_emb.dtype, pk["key"])
+        cache = self.__dict__.setdefault("_ca_kv_cache", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is crossattn_emb:
+            return hit[1]
+        B, M = crossattn_emb.shape[:2]
+        D, nH = self.model_channels, self.num_heads
+        ctx = crossattn_emb.to(torch.bfloat16).permute(1, 0, 2).reshape(M * B, -1).contiguous()  # rows (m, b)
+        per_block = []
+        for blk in pk["blocks"]:
+            kv = ops.gemm_nt(ctx, blk["ca_kv"])  # [M*B, 2D]
+            per_block.append((ops.qk_rmsnorm_rope(kv[:, :D], blk["ca_kn"], None, None, M, B, nH), ops.transpose_v(kv[:, D:], M, B, nH)))
+        while len(cache) >= 4:  # cond / uncond (+ one spare pair): bounded, oldest first
+            cache.pop(next(iter(cache)))
+        cache[key] = (crossattn_emb, per_block)  # holding the tensor keeps its storage (hence the address in the key) alive
+        return per_block
 
     def _modulation(self, emb, ada, lora, n):
         """(shift, scale[, gate]) = chunk_n( W2 . (W1 . SiLU(emb)) + adaln_lora )   (blocks.py:442-447)"""

@@ -118,6 +118,27 @@ def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor
     return out
 
 
+def posemb_layernorm_modulate(x: torch.Tensor, pe_t: torch.Tensor, pe_h: torch.Tensor, pe_w: torch.Tensor, pos_norm: torch.Tensor, T: int,
+                              Hp: int, Wp: int, B: int, shift: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None,
+                              eps: float = 1e-6) -> torch.Tensor:
+    """x [T*Hp*Wp*B, D] += per-block absolute position embedding (IN PLACE), returns LayerNorm(x)*(1+scale)+shift.
+    See g3_posemb_layernorm_modulate_bf16."""
+    rows, D, ldx = _rowmajor2d(x, "x")
+    assert rows == T * Hp * Wp * B
+    for t, n in ((pe_t, T), (pe_h, Hp), (pe_w, Wp)):
+        assert t.dim() == 2 and t.shape[0] >= n and t.shape[1] == D and t.is_contiguous()
+    assert pos_norm.numel() == T * Hp * Wp and pos_norm.is_contiguous()
+    Bm, Ds, ldmod = _rowmajor2d(shift, "shift")
+    assert Ds == D and scale.shape == shift.shape and scale.stride(0) == ldmod
+    if out is None:
+        out = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.g3_posemb_layernorm_modulate_bf16(_dev(x, "x"), ldx, _dev(pe_t, "pe_t"), _dev(pe_h, "pe_h"), _dev(pe_w, "pe_w"),
+                                                     _dev(pos_norm, "pos_norm"), T, Hp, Wp, B, _dev(shift, "shift"), _dev(scale, "scale"), ldmod, Bm,
+                                                     _dev(out, "out"), out.stride(0), D, eps, _stream()), "g3_posemb_layernorm_modulate_bf16")
+    return out
+
+
 def qk_rmsnorm_rope(x: torch.Tensor, weight: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
                     S: int, B: int, H: int, out: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
     """x: [S*B, >=H*128] view (row stride arbitrary), per-head RMSNorm + optional RoPE -> out [S*B, H*128]."""

@@ -97,6 +97,16 @@ int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, c
                             const float* sin_table, void* out, int64_t ld_out, int S, int B, int H, int head_dim,
                             float eps, void* stream);
 
+/* Top of a DiT block in ONE pass over x:  x += extra_per_block_pos_emb  (in place; blocks.py:547-548), then
+ * out = LayerNorm(x) * (1 + scale) + shift  as g3_layernorm_modulate_bf16. The [S*B, D] embedding is not read from memory: it is
+ * rebuilt per row from LearnablePosEmbAxis' three tables pe_t [T,D], pe_h [Hp,D], pe_w [Wp,D] with the reference's bf16 rounding
+ * points (position_embedding.py:218-233; normalize, attention.py:108-124):  bf16(bf16(bf16(pe_t+pe_h)+pe_w) / pos_norm[s]),
+ * pos_norm [T*Hp*Wp] bf16 = 1e-6 + ||.||_2 / sqrt(D) per token. x: [T*Hp*Wp*B, D] rows (s, b), b fastest. With context
+ * parallelism pe_t / pos_norm point at this rank's frames. */
+int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const void* pe_t, const void* pe_h, const void* pe_w,
+                                      const void* pos_norm, int T, int Hp, int Wp, int B, const void* shift, const void* scale,
+                                      int64_t ldmod, int mod_rows, void* out, int64_t ldo, int D, float eps, void* stream);
+
 /* x += y (n % 8 == 0): "x = x + extra_per_block_pos_emb" (blocks.py:547-548). */
 int g3_add_inplace_bf16(void* x, const void* y, int64_t n, void* stream);
 

@@ -114,3 +114,34 @@ def test_dit_full_width_block_vs_oracle():
     print(f"[dit D=4096 H=32, 1 block, 4096 tokens] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
     assert y.shape == y_ref.shape and torch.isfinite(y).all()
     assert rel <= 1.5e-2 and mx <= 6e-2 * float(y_ref.abs().max())
+
+
+def test_cross_attention_kv_cache_follows_context_and_weights():
+    """K / V^T of the cross-attention are cached per (weights, context tensor): a second forward with the same context object reuses
+    them (same output), a different context, an in-place edit of the context, or an in-place weight update must all be seen."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(max_img_h=48, max_img_w=48, max_frames=16, in_channels=81, model_channels=256, num_blocks=2, num_heads=2,
+                                adaln_lora_dim=32, crossattn_emb_channels=128, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=3)
+    B, T, H, W, M = 1, 2, 16, 16, 32
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
+    x, pose, ctx1, ctx2 = rnd(B, 16, T, H, W), rnd(B, 64, T, H, W), rnd(B, M, 128), rnd(B, M, 128)
+    mask = torch.zeros(B, 1, T, H, W, device=dev, dtype=torch.bfloat16)
+    kw = dict(x=x, timesteps=torch.tensor([0.5], device=dev, dtype=torch.bfloat16), crossattn_mask=None, fps=torch.tensor([24.0], device=dev),
+              padding_mask=torch.zeros(B, 1, 8 * H, 8 * W, device=dev, dtype=torch.bfloat16), condition_video_indicator=mask[:, :, :, :1, :1],
+              condition_video_input_mask=mask, condition_video_pose=pose)
+    y1 = net(crossattn_emb=ctx1, **kw)
+    assert len(net._ca_kv_cache) == 1
+    assert torch.equal(net(crossattn_emb=ctx1, **kw), y1) and len(net._ca_kv_cache) == 1    # hit
+    y2 = net(crossattn_emb=ctx2, **kw)
+    assert not torch.equal(y2, y1) and len(net._ca_kv_cache) == 2                            # other context
+    assert torch.equal(net(crossattn_emb=ctx2.clone(), **kw), y2)                            # same values, other tensor: recomputed, same result
+    ctx1.copy_(ctx2)                                                                         # in-place edit -> version bump -> rebuilt
+    assert torch.equal(net(crossattn_emb=ctx1, **kw), y2)
+    with torch.no_grad():
+        net.blocks.block0.blocks._modules["1"].block.attn.to_v._modules["0"].weight.mul_(0.5)  # in-place weight update
+    y3 = net(crossattn_emb=ctx2, **kw)
+    assert not torch.equal(y3, y2)
+    assert len(net._ca_kv_cache) <= 4

@@ -302,6 +302,37 @@ def test_add_inplace():
     assert torch.equal(x, ref)
 
 
+@pytest.mark.parametrize("T,Hp,Wp,B,D", [(3, 4, 5, 1, 256), (2, 3, 7, 2, 4096), (1, 5, 2, 3, 512)])
+def test_posemb_layernorm_modulate_equals_the_two_pass_path(T, Hp, Wp, B, D):
+    """The fused top-of-block kernel (x += per-block absolute position embedding, then LayerNorm + AdaLN modulate) against the two
+    separate passes over a MATERIALISED embedding built with torch in the reference's order (position_embedding.py:218-233, normalize
+    attention.py:108-124): x after the add and the modulated output must both be bit-identical (same bf16 rounding points)."""
+    import math
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(T * 100 + D)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    pe_t, pe_h, pe_w = ((rnd(n, D) * 0.02).to(torch.bfloat16) for n in (T + 2, Hp + 1, Wp + 3))  # tables longer than the used range
+    emb = (pe_t[:T, None, None, :] + pe_h[None, :Hp, None, :]) + pe_w[None, None, :Wp, :]
+    norm = torch.linalg.vector_norm(emb, dim=-1, keepdim=True, dtype=torch.float32)
+    norm = torch.add(1e-6, norm, alpha=math.sqrt(1.0 / D))
+    emb_n = emb / norm.to(emb.dtype)
+    S = T * Hp * Wp
+    table = emb_n.reshape(S, 1, D).expand(-1, B, -1).reshape(S * B, D).contiguous()
+    x = rnd(S * B, D).to(torch.bfloat16)
+    shift, scale = (rnd(B, 3 * D)[:, :D] * 0.3).to(torch.bfloat16), (rnd(B, 3 * D)[:, D:2 * D] * 0.3).to(torch.bfloat16)  # strided [B, D] views
+    x_ref = x.clone()
+    ops.add_inplace(x_ref, table)
+    h_ref = ops.layernorm_modulate(x_ref, shift, scale)
+    x_new = x.clone()
+    h = ops.posemb_layernorm_modulate(x_new, pe_t[:T].contiguous(), pe_h[:Hp].contiguous(), pe_w[:Wp].contiguous(),
+                                      norm.to(torch.bfloat16).reshape(S).contiguous(), T, Hp, Wp, B, shift, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(x_new, x_ref), f"x differs on {int((x_new != x_ref).sum())} elements"
+    assert torch.equal(h, h_ref), f"LN output differs on {int((h != h_ref).sum())} elements"
+    assert not torch.equal(x_new, x)
+
+
 def test_errors_are_loud():
     from gen3c_amd import _lib, ops
     dev = _dev()
