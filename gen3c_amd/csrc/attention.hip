@@ -472,11 +472,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v2_kernel(AttnPara
 //   * no per-cluster s_setprio (it fences the scheduler); the second-dispatched half of the workgroup gets static prio 1.
 // Needs vt_row >= ceil64(S_kv) (true for g3_transpose_v_bf16's output): the V^T tail is read, not guarded.
 // ---------------------------------------------------------------------------------------------------------------
+// ---- hand-counted LDS fragment reads (MW variants). With LDS-DMA (global_load_lds) in flight hipcc (ROCm 7.2) no longer counts its
+// own ds_reads: every wait in the v3 tile loop comes out as `s_waitcnt lgkmcnt(0)` (22 of 22), i.e. each MFMA group also waits for
+// the fragment read issued just before it and the LDS latency the 4-deep ring was built to hide is exposed 11 times per tile. The MW
+// kernels therefore issue the fragment reads themselves (inline asm, invisible to the compiler's counter bookkeeping) and wait with
+// explicit counts: DS operations complete in order, so `lgkmcnt(N)` = "all but the N most recent reads have landed". The wait
+// statement names the fragment it guards as "+v", so the MFMA that consumes the fragment cannot be scheduled above it
+// (cdna_hip_programming.md 5.7, form (ii)).
+template <int OFF> G3_DEVICE void lds_read_frag(bf16x8& dst, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// address of K fragment ks from the one of ks - 4: the swizzled chunk index (2 ks + g) ^ (row & 15) differs in bit 3 only, i.e. the byte
+// address in bit 7 (the LDS ring base is 256-byte aligned - checked at kernel entry). volatile: must not be hoisted out of the tile
+// loop, the point is NOT to hold these addresses in registers (3 VGPRs that otherwise spill into the loop).
+G3_DEVICE uint32_t lds_addr_flip128(uint32_t a) {
+    uint32_t r;
+    asm volatile("v_xor_b32 %0, 0x80, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+template <int N> G3_DEVICE void lds_wait_frag(bf16x8& frag) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N)); }
+template <int I, int N, class F> G3_DEVICE void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 #define G3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSR = 0x100, SGB_TRANS = 0x400;
 
 // QA / QBV: VALU slots pinned behind each MFMA of region A / region B (sched_group_barrier quotas).
-template <int CTX, int QA, int QBV, bool FOLD>
+// Timing ablations (tools/attn_ablate.py; results are garbage): -DG3_AB_ATTN_ABLATE=<bits>  1: no exp2, 2: no row-sum adds, 4: no row-max
+// chain / rescale test, 8: fragments are not read from LDS (one stale register set feeds every MFMA).
+#ifndef G3_AB_ATTN_ABLATE
+#define G3_AB_ATTN_ABLATE 0
+#endif
+template <int CTX, int QA, int QBV, bool FOLD, bool MW = false, int MW_RD = 4, int MW_KREGS = 8>
 __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
@@ -542,9 +574,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             const uint32_t sg = (uint32_t)kv0 / seg_len;
             tile_off = sg * seg_bytes + ((uint32_t)kv0 - sg * seg_len) * 2u;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane0 + tile_off),
+        // ONE 32-bit per-lane byte offset from the uniform head base, exactly like K: selects the SGPR-base form of global_load_lds.
+        // (Written as base + lane + tile the compiler hoists two 64-bit per-lane pointers out of the loop: 4 VGPRs + 64-bit adds.)
+        const uint32_t o0 = v_lane0 + tile_off, o1 = v_lane1 + tile_off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + o0),
                                          (__attribute__((address_space(3))) void*)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + v_lane1 + tile_off),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vbytes + o1),
                                          (__attribute__((address_space(3))) void*)(d + 512 * 8), 16, 0, 0);
     };
 
@@ -554,6 +589,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(krow_perm, 2 * ks + g);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) voff[s4] = v_off(l31, 2 * s4 + g);
+    // MW: per-lane LDS BYTE addresses of the fragments inside slot 0 of each ring (slot / block / step offsets are immediates)
+    const uint32_t lds_k0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)sK;
+    const uint32_t lds_v0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)sV;
+    uint32_t kaddr[8], vaddr[4];
+    if (MW && MW_KREGS < 8 && (lds_k0 & 255u)) __builtin_trap();  // lds_addr_flip128 needs the K ring 256-byte aligned (it is: no static LDS)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds_k0 + 2u * (uint32_t)koff[ks];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) vaddr[s4] = lds_v0 + 2u * (uint32_t)voff[s4];
 
     f32x16 accO[4];
 #pragma unroll
@@ -566,6 +610,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     const int nt = (p.Skv + KVB - 1) / KVB;
 
     auto row_max = [&](const f32x16 (&S)[2]) -> float {  // two independent v_max3 chains (one per 32-kv block)
+        if (G3_AB_ATTN_ABLATE & 4) return 0.f;
         float ma = max3(S[0][0], S[0][1], S[0][2]);
         float mb2 = max3(S[1][0], S[1][1], S[1][2]);
 #pragma unroll
@@ -674,18 +719,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             const int mb = sl >> 1, r0 = (sl & 1) * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float pv = __builtin_amdgcn_exp2f(FOLD ? S_cur[mb][r0 + j] : __builtin_fmaf(S_cur[mb][r0 + j], c, neg_m));
-                psum[sl] += pv;
+                const float sv = FOLD ? S_cur[mb][r0 + j] : __builtin_fmaf(S_cur[mb][r0 + j], c, neg_m);
+                const float pv = (G3_AB_ATTN_ABLATE & 1) ? sv : __builtin_amdgcn_exp2f(sv);
+                if (!(G3_AB_ATTN_ABLATE & 2)) psum[sl] += pv;
                 pb[sl][j] = f32_to_bf16(pv);
             }
         };
 
-        // ---- region A: S_next = K(t+1).Q^T (16 MFMA, fragments 3 ahead)  ||  softmax slices 0 and 1
-        if (has_next) {
+        // MW: ONE fragment ring of RD registers through both regions: fragment n = 0..15 are region A's K fragments, n = 16 + j
+        // region B's V^T fragments; fragment n lives in slot n % RD and is read RD-1 MFMAs before its use, so the first RD-1 V^T reads
+        // are issued while region A's last MFMAs run. (RD = 3 where 4 does not fit the 256-VGPR budget without spilling into the loop -
+        // a scratch reload there is fatal: its vmcnt(0) also waits for the tile's LDS-DMA.)
+        constexpr int RD = MW_RD;
+        bf16x8 fr[RD];
+        // ---- region A: S_next = K(t+1).Q^T (16 MFMA, fragments RD-1 ahead)  ||  softmax slices 0 and 1
+        if (MW && has_next) {
+            constexpr int KS = (par ^ 1) * KVB * HD * 2;  // byte offset of the K slot read here
+            constexpr int VS = par * HD * KVB * 2;        // ... and of the V^T slot region B reads
+            auto k_addr = [&](auto ksc) -> uint32_t {  // ks <= KADDR_REGS-1: register; above: derived from ks - 4
+                constexpr int ks = decltype(ksc)::value;
+                if constexpr (ks < MW_KREGS) return kaddr[ks];
+                else return lds_addr_flip128(kaddr[ks - 4]);
+            };
+            if (!FOLD) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S_next[mb][r] = 0.f;
+            }
+            static_for<0, RD - 1>([&](auto ic) { constexpr int i = decltype(ic)::value; lds_read_frag<KS + 32 * (i >> 3) * HD * 2>(fr[i % RD], k_addr(std::integral_constant<int, (i & 7)>{})); });
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int n = i + RD - 1;  // fragment issued now
+                if constexpr (n < 16) lds_read_frag<KS + 32 * (n >> 3) * HD * 2>(fr[n % RD], k_addr(std::integral_constant<int, (n & 7)>{}));
+                else lds_read_frag<VS + 32 * ((n - 16) & 3) * KVB * 2>(fr[n % RD], vaddr[(n - 16) >> 2]);  // first V^T fragments of region B
+                lds_wait_frag<RD - 1>(fr[i % RD]);  // the RD-1 younger reads (K, then V^T) may still be in flight
+                S_next[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % RD], qf[i & 7], (FOLD && (i & 7) == 0) ? negm : S_next[i >> 3], 0, 0, 0);
+                if (i == 3) softmax_slice(0);
+                if (i == 11) softmax_slice(1);
+            });
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                G3_SGB(SGB_MFMA, 1);
+                G3_SGB(SGB_VALU, QA);
+                G3_SGB(SGB_TRANS, 1);
+            }
+        } else if (has_next) {
             const bf16_t* cK = sK + (par ^ 1) * KVB * HD;
             bf16x8 kf[4];
 #pragma unroll
             for (int i = 0; i < 3; ++i) kf[i] = load_bf16x8(cK + 32 * (i >> 3) * HD + koff[i & 7]);
+            if (G3_AB_ATTN_ABLATE & 8) kf[3] = kf[0];
             if (!FOLD) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
@@ -694,7 +778,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (i + 3 < 16) kf[(i + 3) & 3] = load_bf16x8(cK + 32 * ((i + 3) >> 3) * HD + koff[(i + 3) & 7]);
+                if (i + 3 < 16 && !(G3_AB_ATTN_ABLATE & 8)) kf[(i + 3) & 3] = load_bf16x8(cK + 32 * ((i + 3) >> 3) * HD + koff[(i + 3) & 7]);
                 S_next[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 3], qf[i & 7], (FOLD && (i & 7) == 0) ? negm : S_next[i >> 3], 0, 0, 0);
                 if (i == 3) softmax_slice(0);
                 if (i == 11) softmax_slice(1);
@@ -714,17 +798,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
         G3_JITTER(wave + blockIdx.x + 3, t);
         // ---- region B: O^T += V^T(t).P^T (16 MFMA, fragments 3 ahead) || softmax slices 2,3 || row max of tile t+1
-        {
+        if (MW && has_next) {  // (the last tile of a row block takes the compiler-managed path below: one tile in hundreds, and its
+                               // different register pressure made hipcc spill an in-flight fragment register - see tools/asm_audit.py)
+            constexpr int VS = par * HD * KVB * 2;
+            softmax_slice(2);
+            float mx_next = 0.f;
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int j = i + RD - 1;  // V^T fragment issued now
+                if constexpr (j < 16) lds_read_frag<VS + 32 * (j & 3) * KVB * 2>(fr[(16 + j) % RD], vaddr[j >> 2]);
+                lds_wait_frag<(j < 16) ? RD - 1 : (15 - i)>(fr[(16 + i) % RD]);
+                accO[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(16 + i) % RD], pb[i >> 2], accO[i & 3], 0, 0, 0);
+                if (i == 3) softmax_slice(3);
+                if (has_next && i == 7) mx_next = row_max(S_next);
+            });
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                G3_SGB(SGB_MFMA, 1);
+                G3_SGB(SGB_VALU, QBV);
+                G3_SGB(SGB_TRANS, 1);
+            }
+            l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
+            mx_cur = mx_next;
+        } else {
             const bf16_t* cV = sV + par * HD * KVB;
             bf16x8 vf[4];
             // MFMA order i: step s = i>>2, output block d = i&3
 #pragma unroll
             for (int i = 0; i < 3; ++i) vf[i] = load_bf16x8(cV + 32 * (i & 3) * KVB + voff[i >> 2]);
+            if (G3_AB_ATTN_ABLATE & 8) vf[3] = vf[0];
             softmax_slice(2);
             float mx_next = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (i + 3 < 16) vf[(i + 3) & 3] = load_bf16x8(cV + 32 * ((i + 3) & 3) * KVB + voff[(i + 3) >> 2]);
+                if (i + 3 < 16 && !(G3_AB_ATTN_ABLATE & 8)) vf[(i + 3) & 3] = load_bf16x8(cV + 32 * ((i + 3) & 3) * KVB + voff[(i + 3) >> 2]);
                 accO[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i & 3], pb[i >> 2], accO[i & 3], 0, 0, 0);
                 if (i == 3) softmax_slice(3);
                 if (has_next && i == 7) mx_next = row_max(S_next);
@@ -807,7 +914,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
     int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave (1-3 kept for A/B), 4 (default) = 3 + folded scale/max
-    if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // v3 reads the whole last V^T tile unguarded
+    if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
         // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
         // offsets it forms must stay below 4 GiB, otherwise they wrap silently (e.g. a strided K view of a fused [S*B, 3*4096]
@@ -829,11 +936,13 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     {
       std::lock_guard<std::mutex> attr_lock(attr_mu);
       if (!attr_set[dev_id]) {
-        const void* fns[8] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
-                              reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>)};
-        for (int i = 0; i < 8; ++i) {
+        const void* fns[12] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false, true>)};
+        for (int i = 0; i < 12; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -849,6 +958,9 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     else if (variant == 2) G3_LAUNCH_ATTN(flash_attn_fwd_v2_kernel<0>, flash_attn_fwd_v2_kernel<1>);
     else if (variant == 3) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, false>), (flash_attn_fwd_v3_kernel<1, 6, 8, false>));
     else if (variant == 5) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, true>));  // tests: folded arithmetic at every length
+    else if (variant == 6) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), (flash_attn_fwd_v3_kernel<1, 6, 8, false, true>));  // hand-counted LDS waits
+    else if (variant == 7) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), (flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>));   // tests: MW + fold at every length
+    else if (variant == 8) G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, false, true>)); // tests: MW, unfolded
     else G3_LAUNCH_ATTN((flash_attn_fwd_v3_kernel<0, 6, 8, true>), (flash_attn_fwd_v3_kernel<1, 6, 8, false>));  // short contexts: the fold's prologue does not pay
 #undef G3_LAUNCH_ATTN
     return g3_check_launch("g3_flash_attn_fwd_bf16");

@@ -1,0 +1,92 @@
+"""Audit of the hand-counted LDS reads in the MW attention kernels (cdna_hip_programming.md 5.7, item 1 / form (ii)).
+
+An inline-asm `ds_read_b128` destination counts as written for the compiler the moment the statement ends, so under register pressure
+hipcc may spill, copy or reuse that register BEFORE the data has landed (silent garbage). This script compiles csrc/attention.hip to
+gfx950 assembly and walks every kernel: between an asm `ds_read_b128` and the asm `s_waitcnt lgkmcnt(N)` that retires it (reads retire in
+order: all but the N youngest), no other instruction may name the destination registers. It also reports scratch (spill) reloads inside
+the tile loop: their compiler-inserted `s_waitcnt vmcnt(0)` would also wait for the tile's LDS-DMA.
+
+  python tools/asm_audit.py        -> exit code 1 on any finding (run by tests/test_abi.py-style CPU checks and by hand after edits)
+"""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def audit(asm_text: str):
+    funcs, cur = {}, None
+    for ln in asm_text.split("\n"):
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+flash_attn_fwd\w*kernelI(\w+)EEvNS_10AttnParamsE):", ln)
+        if m:
+            cur = m.group(2)
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(ln)
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+    findings = []
+    for name, v in funcs.items():
+        n_asm_reads = 0
+        pending = {}
+        for i, l in enumerate(v):
+            t = l.strip()
+            in_asm = i > 0 and "ASMSTART" in v[i - 1]
+            if t.startswith("ds_read_b128") and in_asm:
+                n_asm_reads += 1
+                for r in regs(t.split()[1].rstrip(",")):
+                    pending[r] = i
+                continue
+            if t.startswith("s_waitcnt lgkmcnt") and in_asm:
+                n = int(re.search(r"lgkmcnt\((\d+)\)", t).group(1))
+                lines = sorted(set(pending.values()))
+                keep = set(lines[len(lines) - n:]) if n > 0 else set()
+                pending = {r: li for r, li in pending.items() if li in keep}
+                continue
+            if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                pending = {}
+            if not t or t[0] in ";.":
+                continue
+            for tok in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                if regs(tok) & set(pending):
+                    findings.append(f"{name}: line {i}: `{t}` touches an in-flight ds_read destination")
+                    break
+        hdr = [i for i, l in enumerate(v) if "Inner Loop Header" in l]
+        if hdr and n_asm_reads:
+            end = max(i for i, l in enumerate(v) if "in Loop: Header" in l)
+            for i in range(hdr[0], end + 12):
+                if "scratch_load" in v[i]:  # performance, not correctness: reported, does not fail the audit
+                    print(f"note: {name}: line {i}: scratch reload inside the tile loop: `{v[i].strip()}`")
+        if n_asm_reads:
+            print(f"{name}: {n_asm_reads} hand-counted ds_reads audited")
+    return findings
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / "attention.s"
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
+                            str(ROOT / "gen3c_amd" / "csrc" / "attention.hip"), "-o", str(out)], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr)
+            sys.exit(2)
+        findings = audit(out.read_text())
+    for f in findings:
+        print("FINDING:", f)
+    print("asm audit:", "clean" if not findings else f"{len(findings)} finding(s)")
+    sys.exit(1 if findings else 0)
+
+
+if __name__ == "__main__":
+    main()

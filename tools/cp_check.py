@@ -81,8 +81,11 @@ def main():
         full_r = cache.render_cache(w2cs, Ks)
         cache.shard_group = group
         shard_r = cache.render_cache(w2cs, Ks)
-        same = all(torch.equal(a, b) for a, b in zip(full_r, shard_r))
-        print(f"[cp_check] rank {rank}: sharded render (N={n_buf}, foreground_masking={fg}) == replicated: {same}", flush=True)
+        # masks (hence every splat index / occlusion decision) bit-identical; colours are sums of fp32 atomics whose order is not
+        # reproducible between two launches even on one GPU (the reference's index_put_(accumulate=True) has the same property)
+        same = torch.equal(full_r[1], shard_r[1]) and torch.allclose(full_r[0], shard_r[0], rtol=1e-4, atol=1e-5)
+        print(f"[cp_check] rank {rank}: sharded render (N={n_buf}, foreground_masking={fg}) == replicated: {same} "
+              f"(max colour diff {float((full_r[0] - shard_r[0]).abs().max()):.2e})", flush=True)
         good = good and same
     tk = VideoTokenizer(pixel_chunk_duration=n_frames, channels=16, device=dev)
     tk.net.init_random(seed=2)

@@ -1,5 +1,6 @@
 """Interleaved A/B timing of kernel variants at the benchmark shapes (hipEvents on the launch stream).
 usage (GPU box): python tools/microbench.py [gemm] [attn]"""
+import os
 import sys
 from pathlib import Path
 
@@ -56,13 +57,17 @@ def bench_attn():
     out = torch.empty_like(q)
     fl = 4.0 * S * S * 128 * H
     line = []
-    for rnd in range(2):
-        for variant in (3, 4):
+    variants = [int(x) for x in (os.environ.get("G3_MB_ATTN_VARIANTS") or "4,6,8").split(",")]
+    ops.set_option("attn_variant", 4)
+    ref = ops.flash_attn(q, k, vt, S, S, 1, H).float()
+    for rnd in range(3):
+        for variant in variants:
             ops.set_option("attn_variant", variant)
             ms = timeit(lambda: ops.flash_attn(q, k, vt, S, S, 1, H, out=out), 3)
-            line.append((variant, ms, fl / ms / 1e9))
+            err = float((out.float() - ref).abs().max()) if rnd == 0 else 0.0
+            line.append((variant, ms, fl / ms / 1e9, err))
     ops.set_option("attn_variant", 4)
-    print(f"attn S={S} H={H}: " + "  ".join(f"[v{v} {ms:.2f}ms {tf:.0f}TF]" for v, ms, tf in line), flush=True)
+    print(f"attn S={S} H={H}: " + "  ".join(f"[v{v} {ms:.2f}ms {tf:.0f}TF" + (f" maxdiff_vs_v4 {e:.1e}]" if e else "]") for v, ms, tf, e in line), flush=True)
     # cross attention shape
     kc = torch.randn(512, 32 * 128, device=dev).to(torch.bfloat16)
     vc = torch.randn(512, 32 * 128, device=dev).to(torch.bfloat16)
@@ -71,7 +76,7 @@ def bench_attn():
     oc = torch.empty_like(qc)
     flc = 4.0 * S * 512 * 128 * 32
     line = []
-    for variant in (1, 2, 3):
+    for variant in (3, 4, 6, 3, 4, 6):
         ops.set_option("attn_variant", variant)
         ms = timeit(lambda: ops.flash_attn(qc, kc, vtc, S, 512, 1, 32, out=oc), 5)
         line.append((variant, ms, flc / ms / 1e9))
