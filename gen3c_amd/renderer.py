@@ -338,7 +338,9 @@ class Cache3D_BufferSelector(Cache3D_Base):
             pixels_sel, masks_sel = pixels_all, masks_all
         else:
             scores = masks_all.sum(dim=(1, 3, 4, 5))  # [B, N]
-            idx = scores.topk(k=min(self.frame_buffer_max, N), dim=1, largest=True, sorted=True).indices
+            # topk(largest, sorted); ties (equal overlap counts happen: the scores are integers) go to the LOWER buffer index, which is
+            # what the reference's CPU run yields - torch.topk on the GPU breaks them the other way round
+            idx = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :min(self.frame_buffer_max, N)]
             pixels_sel = torch.cat([pixels_all[b:b + 1, :, idx[b]] for b in range(B)], dim=0)
             masks_sel = torch.cat([masks_all[b:b + 1, :, idx[b]] for b in range(B)], dim=0)
         if self.mask_for_max_buffer_model and not render_depth:

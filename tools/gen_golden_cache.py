@@ -102,7 +102,9 @@ def _tv_resize(img, size, interpolation=None, antialias=None):  # torchvision.tr
     return torch.nn.functional.interpolate(img, size=size, mode="bicubic", antialias=True, align_corners=False)
 
 
-sys.modules["torchvision.transforms.functional"] = types.SimpleNamespace(resize=_tv_resize, InterpolationMode=_IM)
+_tvf = types.SimpleNamespace(resize=_tv_resize, InterpolationMode=_IM)
+sys.modules["torchvision.transforms.functional"] = _tvf
+sys.modules["torchvision.transforms"].functional = _tvf  # `import torchvision.transforms.functional as F` resolves through the parent's attribute
 ns = dict(np=np, torch=torch, Cache4D=Cache4D, device_with_rank=lambda d: d, F=torch.nn.functional)
 exec(compile(mod, "<gen3c_persistent.py (reference, selected functions)>", "exec"), ns)
 resize_intrinsics, RefModel = ns["resize_intrinsics"], ns["Gen3cPersistentModel"]
