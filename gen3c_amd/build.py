@@ -19,6 +19,9 @@ LIBDIR = ROOT / "lib"
 OBJDIR = LIBDIR / "obj"
 LIB = LIBDIR / "libgen3c_hip.so"
 ARCH = "gfx950"
+# attention.hip: the SLP vectoriser packs the softmax row-sum adds into v_pk_add_f32 and, in the hand-placed one-wave-per-SIMD kernel, collects
+# them into one serial chain away from where the source puts them (packed fp32 VALU beside MFMAs is slower anyway, MI355X_MICROARCH.md)
+PER_FILE_FLAGS = {"attention.hip": ("-fno-slp-vectorize",)}
 
 
 def _hipcc() -> str:
@@ -49,7 +52,7 @@ def build(verbose: bool = False, force: bool = False, extra_flags: tuple = (), s
     def compile_one(src: Path) -> Path:
         obj = objdir / (src.stem + ".o")
         if force or _newer(src, obj, headers):
-            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+            cmd = [hipcc, *flags, *PER_FILE_FLAGS.get(src.name, ()), "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

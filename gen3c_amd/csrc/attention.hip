@@ -884,6 +884,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
 
 
+#include "attention_w4.hpp"
+
 }  // namespace
 
 static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
@@ -936,13 +938,14 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     {
       std::lock_guard<std::mutex> attr_lock(attr_mu);
       if (!attr_set[dev_id]) {
-        const void* fns[12] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+        const void* fns[14] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>),
-                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false, true>)};
-        for (int i = 0; i < 12; ++i) {
+                               reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false, true>),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<1>)};
+        for (int i = 0; i < 14; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -952,6 +955,12 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 9) {  // one wave per SIMD, 64 query rows per wave (attention_w4.hpp)
+        dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
+        if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_w4_kernel<0>, grid4, dim3(W4_THREADS), smem, st, p);
+        else hipLaunchKernelGGL(flash_attn_fwd_w4_kernel<1>, grid4, dim3(W4_THREADS), smem, st, p);
+        return g3_check_launch("g3_flash_attn_fwd_bf16");
+    }
 #define G3_LAUNCH_ATTN(KERNEL0, KERNEL1) do { if (long_ctx) hipLaunchKernelGGL(KERNEL0, grid, dim3(NTHREADS), smem, st, p); else hipLaunchKernelGGL(KERNEL1, grid, dim3(NTHREADS), smem, st, p); } while (0)
     // VALU quotas (6, 8) per MFMA measured best of {(4,4), (5,6), (6,8)} (profiles/r1_v5_attn_quota_ab.txt)
     if (variant == 1) G3_LAUNCH_ATTN(flash_attn_fwd_kernel<0>, flash_attn_fwd_kernel<1>);

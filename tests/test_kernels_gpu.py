@@ -119,7 +119,7 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all", "attn_w4"])
 def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)

@@ -26,11 +26,12 @@ def regs(tok):
 
 
 def audit(asm_text: str):
-    funcs, cur = {}, None
+    funcs, cur, name_full = {}, None, {}
     for ln in asm_text.split("\n"):
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+flash_attn_fwd\w*kernelI(\w+)EEvNS_10AttnParamsE):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(flash_attn_fwd\w*kernel)I(\w+)EEvNS_10AttnParamsE):", ln)
         if m:
-            cur = m.group(2)
+            cur = m.group(2).replace("flash_attn_fwd_", "") + "<" + m.group(3) + ">"
+            name_full[cur] = m.group(2)
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(ln)
@@ -40,15 +41,24 @@ def audit(asm_text: str):
     for name, v in funcs.items():
         n_asm_reads = 0
         pending = {}
+        in_asm = False
+        owned_agprs = "w4_kernel" in name_full.get(name, "")
         for i, l in enumerate(v):
             t = l.strip()
-            in_asm = i > 0 and "ASMSTART" in v[i - 1]
-            if t.startswith("ds_read_b128") and in_asm:
+            if "ASMSTART" in t:
+                in_asm = True
+                continue
+            if "ASMEND" in t:
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            if in_asm and t.startswith("ds_read_b128"):
                 n_asm_reads += 1
                 for r in regs(t.split()[1].rstrip(",")):
                     pending[r] = i
                 continue
-            if t.startswith("s_waitcnt lgkmcnt") and in_asm:
+            if in_asm and t.startswith("s_waitcnt lgkmcnt"):
                 n = int(re.search(r"lgkmcnt\((\d+)\)", t).group(1))
                 lines = sorted(set(pending.values()))
                 keep = set(lines[len(lines) - n:]) if n > 0 else set()
@@ -56,12 +66,18 @@ def audit(asm_text: str):
                 continue
             if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
                 pending = {}
-            if not t or t[0] in ";.":
-                continue
             for tok in re.findall(r"v\[\d+:\d+\]|v\d+", t):
                 if regs(tok) & set(pending):
                     findings.append(f"{name}: line {i}: `{t}` touches an in-flight ds_read destination")
                     break
+            if owned_agprs and not in_asm:  # the accumulator file a0..a191 belongs to the kernel's asm statements
+                for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", t):
+                    lo = int(m.group(1) or m.group(3))
+                    if lo < 192:
+                        findings.append(f"{name}: line {i}: compiler-generated `{t}` touches an asm-owned AGPR")
+                        break
+            if owned_agprs and t.startswith("scratch_"):
+                findings.append(f"{name}: line {i}: scratch access in a kernel with asm-owned AGPRs: `{t}`")
         hdr = [i for i, l in enumerate(v) if "Inner Loop Header" in l]
         if hdr and n_asm_reads:
             end = max(i for i, l in enumerate(v) if "in Loop: Header" in l)
@@ -69,14 +85,14 @@ def audit(asm_text: str):
                 if "scratch_load" in v[i]:  # performance, not correctness: reported, does not fail the audit
                     print(f"note: {name}: line {i}: scratch reload inside the tile loop: `{v[i].strip()}`")
         if n_asm_reads:
-            print(f"{name}: {n_asm_reads} hand-counted ds_reads audited")
+            print(f"{name}: {n_asm_reads} hand-counted ds_reads audited" + (" + asm-owned AGPRs a0..a191" if owned_agprs else ""))
     return findings
 
 
 def main():
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "attention.s"
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
                             str(ROOT / "gen3c_amd" / "csrc" / "attention.hip"), "-o", str(out)], capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr)
