@@ -70,6 +70,13 @@ template <int OB, int WAIT> G3_DEVICE void w4_pv(const bf16x8& vfrag, const u32x
     else
         asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vfrag), "v"(pfrag), "n"(16 * OB), "n"(16 * OB + 15) : W4_OWNED_AGPRS);
 }
+// one LDS-DMA piece (1 KiB per wave: 64 lanes x 16 B), issued from INSIDE the MFMA stream: at one wave per SIMD the ~60-180 cycles an LDS-DMA
+// instruction takes to issue are matrix-pipe idle time unless an MFMA is executing meanwhile, so the 8 pieces a wave contributes to the next
+// tiles are spread over the first steps of region A instead of being issued back to back at the top of the tile. M0 (the LDS destination)
+// is written in the same statement that reads it (hipcc does not preserve M0 around asm statements, so it does not expect it preserved either).
+G3_DEVICE void w4_dma_piece(uint32_t lds_dst, const char* sbase, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
 // fragment read through an address derived on the spot (bit 7 flipped: K fragment ks from ks - 4, see lds_addr_flip128) - one statement, so
 // that no pad separates the v_xor from the ds_read and the derived address never occupies a register across MFMAs
 template <int OFF> G3_DEVICE void lds_read_frag_flip128(bf16x8& dst, uint32_t addr) {
@@ -80,10 +87,19 @@ template <int OFF> G3_DEVICE void lds_read_frag_flip128(bf16x8& dst, uint32_t ad
 // ---- one asm statement per pipeline STEP. hipcc pads every boundary between two asm statements where the second names a register the
 // first wrote (s_nop) and is free to move its own VALU across them; inside one statement the stream is exactly what is written here.
 //   pair unit k: 2 exp2 + 2 row-sum adds + 1 cvt_pk of two scores -> one packed-bf16 dword of a P fragment
+// (timing ablations, tools/attn_ablate.py: G3_AB_ATTN_ABLATE & 16 drops the pair units, & 32 the fragment reads, & 64 the tile barrier)
+#if G3_AB_ATTN_ABLATE & 16
+#define W4_UNIT(k) "v_mov_b32 %[k" #k "], 0\n\t"
+#else
 #define W4_UNIT(k)                                                                                                                      \
     "v_exp_f32 %[a" #k "], %[x" #k "]\n\tv_exp_f32 %[b" #k "], %[y" #k "]\n\tv_add_f32 %[p" #k "], %[p" #k "], %[a" #k "]\n\t"      \
     "v_add_f32 %[r" #k "], %[r" #k "], %[b" #k "]\n\tv_cvt_pk_bf16_f32 %[k" #k "], %[a" #k "], %[b" #k "]\n\t"
+#endif
+#if G3_AB_ATTN_ABLATE & 32
+#define W4_READ ""
+#else
 #define W4_READ "ds_read_b128 %[nf], %[addr] offset:%c[off]\n\t"
+#endif
 #define W4_WAIT "s_waitcnt lgkmcnt(%c[wn])\n\t"
 #define W4_QK(h) "v_mfma_f32_32x32x16_bf16 %[s" #h "], %[f], a[%c[q" #h "]:%c[e" #h "]], %[s" #h "]\n\t"
 #define W4_QK0(h) "v_mfma_f32_32x32x16_bf16 %[s" #h "], %[f], a[%c[q" #h "]:%c[e" #h "]], %[c" #h "]\n\t"
@@ -226,7 +242,15 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) vaddr[s4] = lds_v0 + 2u * (uint32_t)v_off(l31, 2 * s4 + g);
 
-    float m_run[2], l_run[2] = {0.f, 0.f}, mx_cur[2];
+    float m_run[2], mx_cur[2];
+    // row sums: 8 partial accumulators per half, PERSISTENT over the tiles (zeroing 16 registers and folding them into l every tile costs 32
+    // issue slots per tile that the one-wave stream does not have). [half][step parity x unit slot x lane of the pair]: consecutive
+    // statements never name the same accumulator, and the two units of one step never name the same "+v" variable twice.
+    float psum[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) psum[h][k] = 0.f;
     const int nt = (p.Skv + KVB - 1) / KVB;
 
     auto row_max = [&](const f32x16 (&S)[2]) -> float {  // two independent v_max3 chains (one per 32-kv block), then the lane^32 partner
@@ -291,17 +315,68 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int par = decltype(par_c)::value;
         const int kv0 = t * KVB;
-        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: redo its row max on masked scores
+        // The first fragment reads of the tile go out FIRST: their LDS latency (exposed at one wave per SIMD: step 0 cannot start without
+        // fragment 0) is covered by the row-max chains of this tile's scores, VALU work that needs no LDS operand.
+        constexpr int RD = W4_RD;
+        bf16x8 fr[RD];  // one fragment ring through both regions (fragment n in slot n % RD, read RD-1 steps before its use)
+        if (has_next) {
+            constexpr int KS = (par ^ 1) * KVB * HD * 2;
+            static_for<0, RD - 1>([&](auto ic) { constexpr int n = decltype(ic)::value; lds_read_frag<KS + 32 * (n & 1) * HD * 2>(fr[n % RD], kaddr[n >> 1]); });
+        } else {
+            constexpr int VS = par * HD * KVB * 2;
+            static_for<0, RD - 1>([&](auto ic) { constexpr int j = decltype(ic)::value; lds_read_frag<VS + 32 * (j & 3) * KVB * 2>(fr[(16 + j) % RD], vaddr[j >> 2]); });
+        }
+        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: row max of the masked scores
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 mask_tail(S_cur[h], kv0);
                 mx_cur[h] = row_max(S_cur[h]);
             }
+        } else {
+            // row max of S_cur[h] (relative to m_run) as one serial v_max3 chain over its 32 scores + the lane^32 exchange; one asm statement
+            // per half: hipcc pads every asm statement whose result the next VALU reads with an s_nop, and the chain is serial
+            static_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                const f32x16& s0 = S_cur[h][0];
+                const f32x16& s1 = S_cur[h][1];
+                float m, a, b;
+                asm volatile("v_max3_f32 %0, %3, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\tv_max3_f32 %0, %0, %10, %11\n\t"
+                             "v_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %0, %0, %18, %18\n\t"
+                             "v_max3_f32 %1, %19, %20, %21\n\tv_max3_f32 %1, %1, %22, %23\n\tv_max3_f32 %1, %1, %24, %25\n\t"
+                             "v_max3_f32 %1, %1, %26, %27\n\tv_max3_f32 %1, %1, %28, %29\n\tv_max3_f32 %1, %1, %30, %31\n\tv_max3_f32 %1, %1, %32, %33\n\t"
+                             "v_max3_f32 %0, %0, %1, %34\n\t"
+                             "v_mov_b32 %1, %0\n\tv_mov_b32 %2, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %2\n\tv_max3_f32 %0, %1, %2, %2"
+                             : "=&v"(m), "=&v"(a), "=&v"(b)
+                             : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s0[4]), "v"(s0[5]), "v"(s0[6]), "v"(s0[7]), "v"(s0[8]), "v"(s0[9]), "v"(s0[10]),
+                               "v"(s0[11]), "v"(s0[12]), "v"(s0[13]), "v"(s0[14]), "v"(s0[15]),
+                               "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "v"(s1[4]), "v"(s1[5]), "v"(s1[6]), "v"(s1[7]), "v"(s1[8]), "v"(s1[9]), "v"(s1[10]),
+                               "v"(s1[11]), "v"(s1[12]), "v"(s1[13]), "v"(s1[14]), "v"(s1[15]));
+                mx_cur[h] = m;
+            });
         }
+        // K(t+2) -> slot of K(t) (last read before the previous barrier), V(t+1) -> slot of V(t-1): 8 pieces per wave, issued one per step
+        // inside region A (dma_piece below)
+        uint32_t v_tile_off = 0;
         if (has_next) {
-            if (t + 2 < nt) dma_k(kv0 + 2 * KVB, par);  // K(t+2) -> slot of K(t)   (last read before the previous barrier)
-            dma_v(kv0 + KVB, par ^ 1);                  // V(t+1) -> slot of V(t-1)
+            const uint32_t kvn = (uint32_t)(kv0 + KVB);
+            v_tile_off = kvn * 2u;
+            if (seg_len) {
+                const uint32_t sg = kvn / seg_len;
+                v_tile_off = sg * seg_bytes + (kvn - sg * seg_len) * 2u;
+            }
         }
+        auto dma_piece = [&](auto jc) {  // j = 0..3: K piece j, j = 4..7: V^T piece j - 4
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < 4) {
+                // unconditional (no branch in the stream): past the last tile the source rows are clamped to the last key row and the
+                // destination slot is not read any more
+                const uint32_t o = min(k_lane + (uint32_t)(kv0 + 2 * KVB + 16 * j) * k_row_bytes, k_last);
+                w4_dma_piece(lds_k0 + (uint32_t)(par * KVB * HD * 2 + (wave * 64 + 256 * j) * 16), Kbytes, o);
+            } else {
+                const uint32_t o = v_lane + v_tile_off + 32u * (uint32_t)(j - 4) * v_row_bytes;
+                w4_dma_piece(lds_v0 + (uint32_t)((par ^ 1) * HD * KVB * 2 + (wave * 64 + 256 * (j - 4)) * 16), Vbytes, o);
+            }
+        };
         if (__any(fmaxf(mx_cur[0], mx_cur[1]) > RESCALE_THR)) {  // rare: some row's maximum grew by more than 2^THR since its last rescale
             w4_fence_acc();
             float alpha[2];
@@ -310,7 +385,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
                 const float delta = fmaxf(mx_cur[h], 0.f);
                 alpha[h] = __builtin_amdgcn_exp2f(-delta);
                 m_run[h] += delta;
-                l_run[h] *= alpha[h];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) psum[h][k] *= alpha[h];
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -326,14 +402,6 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
         // issues all 128 exp2 of a tile in front of the first MFMA), hence a __builtin_amdgcn_sched_barrier(0) after every MFMA + VALU piece.
         // Work per tile and wave: 64 MFMA (32 steps x 2 halves), 32 fragment reads, 32 "pair units" (2 exp2 + 2 adds + 1 cvt_pk) and two
         // 19-instruction row-max chains.
-        // row-sum accumulators [half][step parity][unit slot][lane of the pair]: consecutive statements never name the same accumulator (hipcc
-        // pads a statement boundary with an s_nop when the second statement reads a register the first one wrote), and the two units of one
-        // step may belong to the same half - they must not name the same "+v" variable twice
-        float psum[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) psum[h][k] = 0.f;
         u32x4 pb[2][4];  // P fragments (bf16 pairs) of P.V step sl, half h
         // pair unit u = 0..31 in consumption order: slice sl = u >> 3 (P.V step that needs it), half h = (u >> 2) & 1, pair q = u & 3.
         // ONE asm statement: pinned as a block (the row-sum adds otherwise get sunk out of the tile into the next basic block, where 64 of
@@ -350,45 +418,17 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
                          : "v"(S_cur[h][mb][r]), "v"(S_cur[h][mb][r + 1]));
             pb[h][sl][q] = pk;
         };
-        // row max of S_next[h] as one serial v_max3 chain over its 32 scores, cut into 4 pieces (+ the lane^32 exchange in the last);
-        // one asm statement per piece: hipcc pads every asm statement whose result the next VALU reads with an s_nop, and the chain is serial
-        float mchain[2] = {0.f, 0.f}, mx_next[2] = {0.f, 0.f};
-        auto max_piece = [&](auto hc, auto pc) {
-            constexpr int h = decltype(hc)::value, pi = decltype(pc)::value;
-            const f32x16& s0 = S_next[h][0];
-            const f32x16& s1 = S_next[h][1];
-            float& m = mchain[h];
-            if constexpr (pi == 0)
-                asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9"
-                    : "=&v"(m) : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s0[4]), "v"(s0[5]), "v"(s0[6]), "v"(s0[7]), "v"(s0[8]));
-            else if constexpr (pi == 1)
-                asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
-                    : "+v"(m) : "v"(s0[9]), "v"(s0[10]), "v"(s0[11]), "v"(s0[12]), "v"(s0[13]), "v"(s0[14]), "v"(s0[15]), "v"(s1[0]));
-            else if constexpr (pi == 2)
-                asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
-                    : "+v"(m) : "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "v"(s1[4]), "v"(s1[5]), "v"(s1[6]), "v"(s1[7]), "v"(s1[8]));
-            else {
-                float a, b;  // ... the last 7 scores, then the partner lane (lane ^ 32 holds the other 32 keys of the same query row)
-                asm("v_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %9\n\t"
-                    "v_mov_b32 %1, %0\n\tv_mov_b32 %2, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %2\n\tv_max3_f32 %0, %1, %2, %2"
-                    : "+v"(m), "=&v"(a), "=&v"(b) : "v"(s1[9]), "v"(s1[10]), "v"(s1[11]), "v"(s1[12]), "v"(s1[13]), "v"(s1[14]), "v"(s1[15]));
-                mx_next[h] = m;
-            }
-        };
         // operands of pair unit u
         auto ux = [&](auto uc) -> float { constexpr int u = decltype(uc)::value, sl = u >> 3, h = (u >> 2) & 1, q = u & 3; return S_cur[h][sl >> 1][(sl & 1) * 8 + 2 * q]; };
         auto uy = [&](auto uc) -> float { constexpr int u = decltype(uc)::value, sl = u >> 3, h = (u >> 2) & 1, q = u & 3; return S_cur[h][sl >> 1][(sl & 1) * 8 + 2 * q + 1]; };
         auto uput = [&](auto uc, uint32_t pk) { constexpr int u = decltype(uc)::value, sl = u >> 3, h = (u >> 2) & 1, q = u & 3; pb[h][sl][q] = pk; };
 
-        constexpr int RD = W4_RD;
-        bf16x8 fr[RD];  // one fragment ring through both regions (fragment n in slot n % RD, read RD-1 steps before its use)
         // ---- region A: S_next[h] = K(t+1).Q_h^T: 16 fragments, each feeding both halves; step i works on key block mb = i & 1, k-step
         //      ks = i >> 1 (ALTERNATING blocks: two consecutive statements never touch the same accumulator block - no boundary pad)
         //      ||  pair units: one per step in steps 0..11 (units 0..11), two per step in steps 12..15 (units 12..19)
         if (has_next) {
             constexpr int KS = (par ^ 1) * KVB * HD * 2;
             constexpr int VS = par * HD * KVB * 2;
-            static_for<0, RD - 1>([&](auto ic) { constexpr int n = decltype(ic)::value; lds_read_frag<KS + 32 * (n & 1) * HD * 2>(fr[n % RD], kaddr[n >> 1]); });
             static_for<0, 16>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int n = i + RD - 1;  // fragment whose read is issued in this step: K fragment n, or V^T fragment n - 16 of region B
@@ -406,11 +446,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
                                                                       psum[h1][pa + 3]);
                 uput(U0{}, k1);
                 if constexpr (two) uput(U1{}, k2);
+                if constexpr (i < 8) dma_piece(std::integral_constant<int, i>{});
             });
             w4_fence_v(S_next[0][0], S_next[0][1], S_next[1][0], S_next[1][1]);
         } else {
-            constexpr int VS = par * HD * KVB * 2;
-            static_for<0, RD - 1>([&](auto ic) { constexpr int j = decltype(ic)::value; lds_read_frag<VS + 32 * (j & 3) * KVB * 2>(fr[(16 + j) % RD], vaddr[j >> 2]); });
             static_for<0, 20>([&](auto uc) { sm_unit(uc); });
         }
         // ---- region B: O_h^T += V^T(t).P_h^T (16 fragments: step s = i >> 2, output block d = i & 3, each feeding both halves)
@@ -430,20 +469,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
                 w4_step_pv<(i & 3), VS + 32 * (jj & 3) * KVB * 2, rd ? RD - 1 : (15 - i), rd, unit>(fr[(16 + jj) % RD], vaddr[jj >> 2], fr[(16 + i) % RD], pb[0][i >> 2],
                                                                                                  pb[1][i >> 2], ux(U{}), uy(U{}), k1, psum[hu][pa], psum[hu][pa + 1]);
                 if constexpr (unit) uput(U{}, k1);
-                if constexpr (i >= 12) {
-                    if (has_next) {
-                        max_piece(std::integral_constant<int, ((i - 12) >> 1)>{}, std::integral_constant<int, 2 * (i & 1)>{});
-                        max_piece(std::integral_constant<int, ((i - 12) >> 1)>{}, std::integral_constant<int, 2 * (i & 1) + 1>{});
-                    }
-                }
             });
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                l_run[h] += ((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3])) + ((psum[h][4] + psum[h][5]) + (psum[h][6] + psum[h][7]));
-                mx_cur[h] = mx_next[h];
-            }
         }
-        if (has_next) lds_dma_publish_barrier();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
+        if (has_next && !(G3_AB_ATTN_ABLATE & 64)) lds_dma_publish_barrier();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
     };
 
     using True = std::integral_constant<bool, true>;
@@ -465,7 +493,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
     w4_fence_acc();
     static_for<0, 2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
-        const float inv = 1.0f / xor32_sum(l_run[h]);
+        const float inv = 1.0f / xor32_sum(((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3])) + ((psum[h][4] + psum[h][5]) + (psum[h][6] + psum[h][7])));
         const int q_idx = blockIdx.x * W4_BQ + wave * 64 + 32 * h + l31;
         bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
         static_for<0, 16>([&](auto cc) {  // (d, q4): 4 consecutive output dims per store

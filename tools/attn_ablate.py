@@ -4,12 +4,14 @@ GPU box:                                       python tools/attn_ablate.py      
 Bits (G3_AB_ATTN_ABLATE, csrc/attention.hip): 1 no exp2, 2 no row-sum adds, 4 no row-max chain / rescale test, 8 no LDS fragment reads."""
 import ctypes as C
 import math
+import os
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-CASES = [3, 4, 7, 8, 15]
+CASES = [int(x) for x in (os.environ.get('G3_ABLATE_CASES') or '3,4,7,8,15').split(',')]
+VARIANT = int(os.environ.get('G3_ABLATE_VARIANT', '4'))
 
 if "--build" in sys.argv:
     from gen3c_amd import build
@@ -37,6 +39,8 @@ st = torch.cuda.current_stream().cuda_stream
 fl = 4.0 * S * S * 128 * H
 legend = {"product": "full kernel", "ablate=3": "no exp2, no row-sum adds", "ablate=4": "no row-max chain", "ablate=7": "no softmax VALU except cvt_pk",
           "ablate=8": "no LDS fragment reads", "ablate=15": "MFMA + cvt_pk + LDS-DMA + barriers only"}
+for nm, lib in libs:
+    lib.g3_set_option(b"attn_variant", VARIANT)
 for rnd in range(2):
     for nm, lib in libs:
         def run():
@@ -44,4 +48,4 @@ for rnd in range(2):
                                             out.data_ptr(), H * 128, H * 128, 128, S, S, 1, H, 128, 1.0 / math.sqrt(128), st)
             assert rc == 0
         ms = timeit(run, 3)
-        print(f"{nm:10s} {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF-equivalent   ({legend[nm]})", flush=True)
+        print(f"{nm:10s} {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF-equivalent   ({legend.get(nm, 'w4: 16 no pair units, 32 no fragment reads, 64 no tile barrier')})", flush=True)
