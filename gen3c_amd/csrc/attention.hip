@@ -885,6 +885,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
 
 #include "attention_w4.hpp"
+#include "attention_w4b.hpp"
 
 }  // namespace
 
@@ -938,14 +939,15 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     {
       std::lock_guard<std::mutex> attr_lock(attr_mu);
       if (!attr_set[dev_id]) {
-        const void* fns[14] = {reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
+        const void* fns[15] = {reinterpret_cast<const void*>(&flash_attn_fwd_w4b_kernel),
+                               reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false, true>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<1>)};
-        for (int i = 0; i < 14; ++i) {
+        for (int i = 0; i < 15; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -955,6 +957,12 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 10 && (Skv % KVB)) variant = 9;  // w4b: whole 64-key tiles only
+    if (variant == 10) {  // w4 with the trimmed issue stream (attention_w4b.hpp)
+        dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
+        hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel, grid4, dim3(W4_THREADS), smem, st, p);
+        return g3_check_launch("g3_flash_attn_fwd_bf16");
+    }
     if (variant == 9) {  // one wave per SIMD, 64 query rows per wave (attention_w4.hpp)
         dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
         if (long_ctx) hipLaunchKernelGGL(flash_attn_fwd_w4_kernel<0>, grid4, dim3(W4_THREADS), smem, st, p);

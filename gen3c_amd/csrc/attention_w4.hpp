@@ -75,6 +75,7 @@ template <int OB, int WAIT> G3_DEVICE void w4_pv(const bf16x8& vfrag, const u32x
 // tiles are spread over the first steps of region A instead of being issued back to back at the top of the tile. M0 (the LDS destination)
 // is written in the same statement that reads it (hipcc does not preserve M0 around asm statements, so it does not expect it preserved either).
 G3_DEVICE void w4_dma_piece(uint32_t lds_dst, const char* sbase, uint32_t voff) {
+    if (G3_AB_ATTN_ABLATE & 128) return;  // timing ablation: no LDS-DMA in the stream (tiles keep their prologue contents)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 // fragment read through an address derived on the spot (bit 7 flipped: K fragment ks from ks - 4, see lds_addr_flip128) - one statement, so
@@ -87,7 +88,8 @@ template <int OFF> G3_DEVICE void lds_read_frag_flip128(bf16x8& dst, uint32_t ad
 // ---- one asm statement per pipeline STEP. hipcc pads every boundary between two asm statements where the second names a register the
 // first wrote (s_nop) and is free to move its own VALU across them; inside one statement the stream is exactly what is written here.
 //   pair unit k: 2 exp2 + 2 row-sum adds + 1 cvt_pk of two scores -> one packed-bf16 dword of a P fragment
-// (timing ablations, tools/attn_ablate.py: G3_AB_ATTN_ABLATE & 16 drops the pair units, & 32 the fragment reads, & 64 the tile barrier)
+// (timing ablations, tools/attn_ablate.py: G3_AB_ATTN_ABLATE & 16 drops the pair units, & 32 the fragment reads, & 64 the tile barrier,
+// & 128 the in-stream LDS-DMA pieces, & 256 the row-max chains)
 #if G3_AB_ATTN_ABLATE & 16
 #define W4_UNIT(k) "v_mov_b32 %[k" #k "], 0\n\t"
 #else
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4_kernel(AttnPa
             constexpr int VS = par * HD * KVB * 2;
             static_for<0, RD - 1>([&](auto ic) { constexpr int j = decltype(ic)::value; lds_read_frag<VS + 32 * (j & 3) * KVB * 2>(fr[(16 + j) % RD], vaddr[j >> 2]); });
         }
-        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: row max of the masked scores
+        if (G3_AB_ATTN_ABLATE & 256) {  // timing ablation: no row-max chains
+            mx_cur[0] = mx_cur[1] = 0.f;
+        } else if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: row max of the masked scores
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 mask_tail(S_cur[h], kv0);

@@ -119,7 +119,7 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all", "attn_w4"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all", "attn_w4", "attn_w4b"])
 def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)
@@ -231,6 +231,50 @@ def test_flash_attn_segmented_vt_matches_plain():
         segs = torch.stack([ops.transpose_v(v[i * S_loc * B:(i + 1) * S_loc * B], S_loc, B, H) for i in range(n)])  # [n,B,H,128,ld]
         out = ops.flash_attn(q, k, segs.contiguous(), Sq, Skv, B, H)
         assert torch.equal(out, ref), (Sq, S_loc, n, B, H)
+
+
+@pytest.mark.parametrize("variant", [9, 10], ids=["attn_w4", "attn_w4b"])
+def test_flash_attn_one_wave_per_simd_long_context(variant):
+    """The one-wave-per-SIMD kernels (attention_w4.hpp / attention_w4b.hpp) on what their hand-laid tile stream has to get right: many tiles
+    (ring slots and LDS-DMA bases wrap), keys whose scores tower over the running maximum late in the context (rescale branch with fragment
+    reads in flight), an odd and an even number of tiles, query counts that do not fill the last workgroup, batch > 1, strided views, and
+    V^T handed over in key segments (bit-identical to the contiguous layout)."""
+    from gen3c_amd import ops
+    dev = _dev()
+    ops.set_option("attn_variant", variant)
+    try:
+        g = torch.Generator(device=dev).manual_seed(1234 + variant)
+        for (Sq, Skv, B, H, qscale, spikes) in [(300, 4160, 1, 2, 1.0, ()), (256, 3008, 2, 2, 1.0, (2900,)), (96, 2624, 1, 1, 6.0, (70, 2500)), (520, 8256, 1, 3, 1.0, (40, 8200)),
+                                                (64, 64, 1, 1, 1.0, ()), (130, 128, 1, 2, 1.0, (100,))]:
+            W = H * 128
+            big = torch.randn(max(Sq, Skv) * B, 3 * W, device=dev, generator=g).to(torch.bfloat16)
+            q, k, v = (big[:Sq * B, :W] * qscale).to(torch.bfloat16), big[:Skv * B, W:2 * W], big[:Skv * B, 2 * W:]
+            if spikes:
+                k = k.clone()
+                for i, sp in enumerate(spikes):  # keys aligned with the queries: scores far above everything before them, growing
+                    k.view(Skv, B, H, 128)[sp] = (q.view(Sq, B, H, 128).float().mean(0) * (4 + 3 * i)).to(torch.bfloat16)
+            out = ops.flash_attn(q, k, ops.transpose_v(v, Skv, B, H), Sq, Skv, B, H)
+            q4, k4, v4 = (t.float().reshape(-1, B, H, 128).permute(1, 2, 0, 3) for t in (q, k, v))
+            ref = (torch.softmax(q4 @ k4.transpose(-1, -2) / math.sqrt(128), -1) @ v4).permute(2, 0, 1, 3).reshape(Sq * B, W)
+            r = _rel_l2(out, ref)
+            print(f"[attn variant {variant} Sq={Sq} Skv={Skv} B={B} H={H}] rel_l2={r:.3e}")
+            assert torch.isfinite(out.float()).all() and r < 1e-2, (Sq, Skv, B, H, r)
+        for (Sq, S_loc, n, B, H) in [(320, 128, 4, 1, 2), (200, 64, 8, 2, 3), (300, 1408, 3, 1, 2)]:
+            Skv = S_loc * n
+            g = torch.Generator(device=dev).manual_seed(Sq + Skv)
+            q = torch.randn(Sq * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+            k = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+            v = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+            ref = ops.flash_attn(q, k, ops.transpose_v(v, Skv, B, H), Sq, Skv, B, H)
+            segs = torch.stack([ops.transpose_v(v[i * S_loc * B:(i + 1) * S_loc * B], S_loc, B, H) for i in range(n)])
+            out = ops.flash_attn(q, k, segs.contiguous(), Sq, Skv, B, H)
+            assert torch.equal(out, ref), (Sq, S_loc, n, B, H)
+            ops.set_option("attn_variant", 4)
+            base = ops.flash_attn(q, k, ops.transpose_v(v, Skv, B, H), Sq, Skv, B, H)
+            ops.set_option("attn_variant", variant)
+            assert _rel_l2(out, base.float()) < 4e-3
+    finally:
+        ops.set_option("attn_variant", 4)
 
 
 @pytest.mark.parametrize("rows,D,B", [(64, 128, 1), (1000, 256, 2), (4096, 4096, 1), (77, 8192, 1)])

@@ -28,9 +28,9 @@ def regs(tok):
 def audit(asm_text: str):
     funcs, cur, name_full = {}, None, {}
     for ln in asm_text.split("\n"):
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(flash_attn_fwd\w*kernel)I(\w+)EEvNS_10AttnParamsE):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(flash_attn_fwd\w*kernel)(?:I(\w+)EEv|E)NS_10AttnParamsE):", ln)
         if m:
-            cur = m.group(2).replace("flash_attn_fwd_", "") + "<" + m.group(3) + ">"
+            cur = m.group(2).replace("flash_attn_fwd_", "") + "<" + (m.group(3) or "") + ">"
             name_full[cur] = m.group(2)
             funcs[cur] = []
         elif cur is not None:
@@ -42,9 +42,21 @@ def audit(asm_text: str):
         n_asm_reads = 0
         pending = {}
         in_asm = False
-        owned_agprs = "w4_kernel" in name_full.get(name, "")
+        owned_agprs = "w4" in name_full.get(name, "")
+        owned_limit = 256 if "w4b" in name_full.get(name, "") else 192  # w4b also owns the fragment ring a[192:255]
+        hdr0 = [i for i, l in enumerate(v) if "Inner Loop Header" in l]
+        loop_lo = hdr0[0] if hdr0 else len(v)
+        loop_hi = max([i for i, l in enumerate(v) if "in Loop: Header" in l] + [0]) + 400
+        last_trans = None  # (dst register, line) of a compiler-generated transcendental with no instruction after it yet
         for i, l in enumerate(v):
             t = l.strip()
+            if t and t[0] not in ";." and "ASM" not in t:
+                # hipcc pads a transcendental result read by the NEXT VALU instruction (gfx940+ trans forwarding hazard) only when it
+                # generated the reader itself; a reader inside an inline-asm statement gets a stale value
+                if last_trans is not None and in_asm and re.search(r"\b" + last_trans[0] + r"\b", t.split(None, 1)[1] if " " in t else ""):
+                    findings.append(f"{name}: line {i}: asm `{t}` reads {last_trans[0]} straight after the compiler-generated transcendental that writes it")
+                m_tr = re.match(r"(v_exp_|v_log_|v_rcp_|v_rsq_|v_sqrt_|v_sin_|v_cos_)\S*\s+(v\d+)", t)
+                last_trans = (m_tr.group(2), i) if (m_tr and not in_asm) else None
             if "ASMSTART" in t:
                 in_asm = True
                 continue
@@ -73,9 +85,12 @@ def audit(asm_text: str):
             if owned_agprs and not in_asm:  # the accumulator file a0..a191 belongs to the kernel's asm statements
                 for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", t):
                     lo = int(m.group(1) or m.group(3))
-                    if lo < 192:
+                    if lo < owned_limit:
                         findings.append(f"{name}: line {i}: compiler-generated `{t}` touches an asm-owned AGPR")
                         break
+            if owned_agprs and loop_lo <= i <= loop_hi and re.match(r"s_(buffer_)?load_", t):
+                # the hand-counted lgkmcnt(N) waits assume LDS reads are the only LGKM operations in flight (SMEM returns out of order)
+                findings.append(f"{name}: line {i}: scalar memory load near the tile loop of a kernel with hand-counted lgkmcnt waits: `{t}`")
             if owned_agprs and t.startswith("scratch_"):
                 findings.append(f"{name}: line {i}: scratch access in a kernel with asm-owned AGPRs: `{t}`")
         hdr = [i for i, l in enumerate(v) if "Inner Loop Header" in l]
@@ -85,7 +100,7 @@ def audit(asm_text: str):
                 if "scratch_load" in v[i]:  # performance, not correctness: reported, does not fail the audit
                     print(f"note: {name}: line {i}: scratch reload inside the tile loop: `{v[i].strip()}`")
         if n_asm_reads:
-            print(f"{name}: {n_asm_reads} hand-counted ds_reads audited" + (" + asm-owned AGPRs a0..a191" if owned_agprs else ""))
+            print(f"{name}: {n_asm_reads} hand-counted ds_reads audited" + (f" + asm-owned AGPRs a0..a{owned_limit - 1}" if owned_agprs else ""))
     return findings
 
 

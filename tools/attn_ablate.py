@@ -48,4 +48,4 @@ for rnd in range(2):
                                             out.data_ptr(), H * 128, H * 128, 128, S, S, 1, H, 128, 1.0 / math.sqrt(128), st)
             assert rc == 0
         ms = timeit(run, 3)
-        print(f"{nm:10s} {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF-equivalent   ({legend.get(nm, 'w4: 16 no pair units, 32 no fragment reads, 64 no tile barrier')})", flush=True)
+        print(f"{nm:10s} {ms:7.3f} ms {fl / ms / 1e9:6.0f} TF-equivalent   ({legend.get(nm, 'w4: 16 no pair units, 32 no fragment reads, 64 no tile barrier, 128 no in-stream LDS-DMA, 256 no row-max chains')})", flush=True)
