@@ -123,7 +123,7 @@ def main():
         env.setdefault("OMP_NUM_THREADS", "8")
         sys.exit(subprocess.call(self_launch_argv(args.gpus, sys.argv[1:]), env=env))
 
-    from gen3c_amd import ops
+    from gen3c_amd import _lib, ops
     from gen3c_amd.dit import VideoExtendGeneralDIT
     from gen3c_amd.parallel import init_distributed, parallel_state
     from gen3c_amd.sampler import Gen3CDenoiser, VideoExtendCondition, add_condition_video_indicator_and_video_input_mask
@@ -212,15 +212,19 @@ def main():
         avg_ms = sum(ms for _, ms in self_attn) / len(self_attn)
         flops_launch = sum(4.0 * m["Sq"] * m["Skv"] * m["H"] * 128 * m["B"] for m, _ in self_attn) / len(self_attn)
         ach = flops_launch / (avg_ms * 1e-3) / 1e12
+        m0 = self_attn[0][0]
+        kname = _lib.load().g3_flash_attn_kernel_name(m0["Sq"], m0["Skv"], m0["B"], m0["H"]).decode()
         traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape), if present
-        try:
-            tj = json.loads((ROOT / "profiles" / "r1_attn_traffic.json").read_text())
-            m0 = self_attn[0][0]
-            if world == 1 and tj["shape"] == {"Sq": m0["Sq"], "Skv": m0["Skv"], "H": m0["H"], "B": m0["B"]}:
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        roof = dict(bound="mfma", kernel="flash_attn_fwd_v3_kernel<0,6,8,true>", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+        for tf in ("r2_attn_traffic.json", "r1_attn_traffic.json"):
+            try:
+                tj = json.loads((ROOT / "profiles" / tf).read_text())
+                same_kernel = tj["kernel"].replace(" ", "").split("<")[0] == kname.replace(" ", "").split("<")[0]
+                if world == 1 and same_kernel and tj["shape"] == {"Sq": m0["Sq"], "Skv": m0["Skv"], "H": m0["H"], "B": m0["B"]}:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    break
+            except Exception:
+                continue
+        roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
                     flops_per_launch=flops_launch)
 

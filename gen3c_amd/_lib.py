@@ -28,6 +28,7 @@ SIGNATURES = {
     "g3_flash_attn_fwd_kvseg_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i64, vp, i64, i64, i64, i32, i32, i32,
                                      i32, i32, f32, vp],
     "g3_gemv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp],
+    "g3_flash_attn_kernel_name": [i32, i32, i32, i32],
     "g3_flash_attn_fwd_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32,
                                i32, i32, f32, vp],
     "g3_transpose_v_bf16": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
@@ -57,7 +58,7 @@ SIGNATURES = {
     "g3_edm_prepare_input_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, vp],
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }
-_RESTYPES = {"g3_last_error": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t}
+_RESTYPES = {"g3_last_error": C.c_char_p, "g3_flash_attn_kernel_name": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t}
 
 
 class Gen3cHipError(RuntimeError):

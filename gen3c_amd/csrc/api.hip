@@ -28,7 +28,7 @@ static int env_int(const char* name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 int g3_opt_gemm_regstage = env_int("G3_GEMM_REGSTAGE", 0);
-int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 4);
+int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 0);  // 0 = automatic (attention.hip: flash_attn_launch)
 int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 int g3_opt_gemm_wide_store = env_int("G3_GEMM_WIDE_STORE", 1);
 int g3_opt_splat_tiled = env_int("G3_SPLAT_TILED", 1);

@@ -889,6 +889,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
 }  // namespace
 
+static int attn_resolve_variant(int Sq, int Skv, int B, int H) {
+    int variant = g3_opt_attn_variant;
+    if (variant == 0) {
+        const long n_wg = (long)((Sq + 255) / 256) * H * B;
+        const long rounds = (n_wg + 255) / 256;
+        const bool even_fill = n_wg * 100 >= rounds * 256 * 93;  // <= 7 % of the last round idle (one workgroup per CU)
+        variant = (Skv > 2048 && (Skv % KVB) == 0 && even_fill) ? 10 : 4;
+    }
+    if (variant == 10 && (Skv % KVB)) variant = 9;  // w4b: whole 64-key tiles only
+    return variant;
+}
+
+extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) {
+    const bool long_ctx = Skv > 2048;
+    switch (attn_resolve_variant(Sq, Skv, B, H)) {
+        case 1: return long_ctx ? "flash_attn_fwd_kernel<0>" : "flash_attn_fwd_kernel<1>";
+        case 2: return long_ctx ? "flash_attn_fwd_v2_kernel<0>" : "flash_attn_fwd_v2_kernel<1>";
+        case 3: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, false>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false>";
+        case 5: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true>" : "flash_attn_fwd_v3_kernel<1, 6, 8, true>";
+        case 6: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false, true>";
+        case 7: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>" : "flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>";
+        case 8: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, false, true>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false, true>";
+        case 9: return long_ctx ? "flash_attn_fwd_w4_kernel<0>" : "flash_attn_fwd_w4_kernel<1>";
+        case 10: return "flash_attn_fwd_w4b_kernel";
+        default: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false>";
+    }
+}
+
 static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
                              int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
                              int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H,
@@ -916,7 +944,10 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
-    int variant = g3_opt_attn_variant;  // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave (1-3 kept for A/B), 4 (default) = 3 + folded scale/max
+    // 0 (default) = automatic: w4b (10) on long contexts made of whole 64-key tiles whose 256-row workgroups fill the chip's 256 CUs evenly,
+    // else 4. Explicit values are kept for A/B runs and tests: 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave,
+    // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b.
+    int variant = attn_resolve_variant(Sq, Skv, B, H);
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
         // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
@@ -957,7 +988,6 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 10 && (Skv % KVB)) variant = 9;  // w4b: whole 64-key tiles only
     if (variant == 10) {  // w4 with the trimmed issue stream (attention_w4b.hpp)
         dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
         hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel, grid4, dim3(W4_THREADS), smem, st, p);

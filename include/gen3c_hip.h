@@ -71,6 +71,10 @@ int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_
                            int64_t vt_head, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv,
                            int B, int H, int head_dim, float softmax_scale, void* stream);
 
+/* Name of the kernel g3_flash_attn_fwd_bf16 launches for this problem under the current "attn_variant" option (0 = automatic choice
+ * between the 8-wave and the one-wave-per-SIMD kernels): for profilers and bench.py's roofline line, never needed to run the op. */
+const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H);
+
 /* Same, with V^T stored in KEY SEGMENTS: keys [s*vt_seg_len, (s+1)*vt_seg_len) live in the block at vt + s*vt_seg_stride (each block
  * laid out as above with its own vt_row >= vt_seg_len). vt_seg_len must be a multiple of 64 and divide S_kv. This is what a rank-major
  * all-gather of per-rank V^T shards produces under context parallelism (module/parallel.py:110-163 gathers; TE's CP attention is the

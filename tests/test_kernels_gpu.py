@@ -124,7 +124,7 @@ def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)
     yield request.param
-    ops.set_option("attn_variant", 4)
+    ops.set_option("attn_variant", 0)
 
 
 @pytest.mark.parametrize("Sq,Skv,B,H", [(256, 256, 1, 1), (512, 512, 1, 2), (300, 200, 1, 2), (96, 40, 2, 3), (1024, 512, 1, 4),
@@ -274,7 +274,7 @@ def test_flash_attn_one_wave_per_simd_long_context(variant):
             ops.set_option("attn_variant", variant)
             assert _rel_l2(out, base.float()) < 4e-3
     finally:
-        ops.set_option("attn_variant", 4)
+        ops.set_option("attn_variant", 0)
 
 
 @pytest.mark.parametrize("rows,D,B", [(64, 128, 1), (1000, 256, 2), (4096, 4096, 1), (77, 8192, 1)])

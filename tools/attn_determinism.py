@@ -26,4 +26,4 @@ for variant in (3, 4):
         o3 = o
     else:
         print("variant 4 vs 3 rel-l2:", float((o.float() - o3.float()).norm() / o3.float().norm()))
-ops.set_option("attn_variant", 4)
+ops.set_option("attn_variant", 0)

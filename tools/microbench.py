@@ -58,7 +58,7 @@ def bench_attn():
     fl = 4.0 * S * S * 128 * H
     line = []
     variants = [int(x) for x in (os.environ.get("G3_MB_ATTN_VARIANTS") or "4,6,8").split(",")]
-    ops.set_option("attn_variant", 4)
+    ops.set_option("attn_variant", 0)
     ref = ops.flash_attn(q, k, vt, S, S, 1, H).float()
     for rnd in range(3):
         for variant in variants:
@@ -66,7 +66,7 @@ def bench_attn():
             ms = timeit(lambda: ops.flash_attn(q, k, vt, S, S, 1, H, out=out), 3)
             err = float((out.float() - ref).abs().max()) if rnd == 0 else 0.0
             line.append((variant, ms, fl / ms / 1e9, err))
-    ops.set_option("attn_variant", 4)
+    ops.set_option("attn_variant", 0)
     print(f"attn S={S} H={H}: " + "  ".join(f"[v{v} {ms:.2f}ms {tf:.0f}TF" + (f" maxdiff_vs_v4 {e:.1e}]" if e else "]") for v, ms, tf, e in line), flush=True)
     # cross attention shape
     kc = torch.randn(512, 32 * 128, device=dev).to(torch.bfloat16)
@@ -80,7 +80,7 @@ def bench_attn():
         ops.set_option("attn_variant", variant)
         ms = timeit(lambda: ops.flash_attn(qc, kc, vtc, S, 512, 1, 32, out=oc), 5)
         line.append((variant, ms, flc / ms / 1e9))
-    ops.set_option("attn_variant", 4)
+    ops.set_option("attn_variant", 0)
     print("cross-attn S=56320 M=512 H=32: " + "  ".join(f"[v{v} {ms:.3f}ms {tf:.0f}TF]" for v, ms, tf in line), flush=True)
 
 
