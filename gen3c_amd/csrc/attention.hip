@@ -492,12 +492,6 @@ G3_DEVICE uint32_t lds_addr_flip128(uint32_t a) {
     return r;
 }
 template <int N> G3_DEVICE void lds_wait_frag(bf16x8& frag) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N)); }
-template <int I, int N, class F> G3_DEVICE void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 #define G3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSR = 0x100, SGB_TRANS = 0x400;

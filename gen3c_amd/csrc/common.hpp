@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the GEN3C denoising path.
 // Wave = 64 lanes everywhere. No portability shims: this code only targets gfx950.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -62,6 +63,14 @@ G3_DEVICE float gelu_erf_fast(float x) {
     const float a = ((poly * t) * ex) * ax;
     return fmaxf(x, 0.0f) - a;
 }
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F> G3_DEVICE void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // Race screen: -DG3_AB_JITTER=<n> (tools/ab_flags.py) makes pseudo-randomly chosen waves sleep n*64 cycles at tile / phase
 // boundaries. A kernel whose LDS hand-offs are correctly fenced gives bit-identical results under any such timing.
 #ifdef G3_AB_JITTER

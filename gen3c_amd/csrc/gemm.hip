@@ -19,6 +19,7 @@
 //     the weight panel).
 #include "common.hpp"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -740,10 +741,15 @@ int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
     return g3_check_launch(what);
 }
 
+#include "gemm_w4.hpp"
+
 template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
-    if (glds && g3_opt_gemm_pingpong == 2) return launch_pp<EPI, 2, CONV>(p, stream, what);
+    if constexpr (!CONV) {  // one wave per SIMD (gemm_w4.hpp): whole 64-wide K tiles, at least two, full-line epilogue
+        if (glds && g3_opt_gemm_pingpong == 3 && p.wide_store && p.K >= 2 * BK) return launch_w4<EPI>(p, stream, what);
+    }
+    if (glds && g3_opt_gemm_pingpong >= 2) return launch_pp<EPI, 2, CONV>(p, stream, what);
     if constexpr (!CONV) {
         if (glds && g3_opt_gemm_pingpong) return launch_pp<EPI, 4, false>(p, stream, what);
     }

@@ -1,0 +1,268 @@
+// Included by gemm.hip inside its anonymous namespace (shares GemmParams, lds_off, store_tile_lds, the XCD-aware tile order).
+//
+// gemm_bf16_nt_w4_kernel: the block GEMM with ONE wave per SIMD. Workgroup = 4 waves = one 256 (token) x 256 (feature) tile, each wave a
+// 128 x 128 quadrant: 16 accumulator blocks of 32 x 32 = all 256 AGPRs, every operand fragment feeds FOUR MFMAs (the 8-wave ping-pong kernel:
+// two) - half the LDS operand traffic per flop, which is what the kernel pays for at the 1 400 W cap. Nothing hides a wave's own LDS-DMA issue
+// cost or LDS latency at one wave per SIMD, so the instruction stream of a K tile is laid out by hand, as in csrc/attention_w4b.hpp:
+//   * asm-owned registers, by literal name: a[0:255] accumulators (block (i, j): features 32 i.., tokens 32 j.., at a[16 (4 j + i) : +15]),
+//     v[192:255] two buffers of 8 operand fragments (W_0..3, T_0..3 of one 16-wide k-step);
+//   * a K tile (64) = 4 k-step statements of 16 MFMAs; the fragments of k-step s + 1 are read while k-step s multiplies (s = 3: the first
+//     k-step of the NEXT tile, from the other LDS stage), so no LDS latency is exposed;
+//   * 2 LDS stages of 64 KiB ([256 feature rows][64 k] + [256 token rows][64 k], chunk index XOR-swizzled as in the other kernels). ONE barrier
+//     per K tile, after k-step 2, behind `s_waitcnt vmcnt(0) lgkmcnt(0)`: it publishes tile t + 1 (LDS-DMA issued during k-step 3 of tile t - 1
+//     and k-step 0 of tile t) and certifies that every wave holds the k-step-3 fragments of tile t in registers, which frees tile t's stage:
+//     its refill with tile t + 2 starts in k-step 3 (weight rows) and completes in k-step 0 of tile t + 1 (token rows) - every LDS-DMA piece
+//     has >= 2 k-steps (>= 1 000 cycles) to land;
+//   * an LDS-DMA piece is `s_add m0` + `global_load_lds_dwordx4` behind an MFMA; its 16 per-lane source offsets are loop-invariant VGPRs
+//     (rows clamped to the matrix, so M / N tails read valid memory and are never stored), the K position is the wave-uniform base.
+// Needs K % 64 == 0, K >= 128 and the full-line epilogue's alignment (host: launch()); everything else runs on the ping-pong kernel.
+
+#define GW4_ACC_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+#define GW4_FRAG_VGPRS "v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255"
+#define GW4_OWNED GW4_ACC_AGPRS, GW4_FRAG_VGPRS
+
+constexpr int GW4_THREADS = 256;
+constexpr int GW4_FRAG0 = 192;               // buffer b, fragment f (0..3 weights, 4..7 tokens) at v[192 + 32 b + 4 f : +3]
+constexpr int GW4_STAGE_BYTES = 65536;       // [W tile 32 KiB][T tile 32 KiB]
+constexpr int GW4_T_OFF = 32768;
+
+template <int R> G3_DEVICE void gw4_acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"n"(R) : GW4_OWNED); }
+template <int R> G3_DEVICE float gw4_acc_read() {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "n"(R) : GW4_ACC_AGPRS);
+    return v;
+}
+
+// timing ablations (tools/gemm_ablate_w4.py; results are garbage): -DG3_AB_GW4_ABLATE=<bits>  1: the barrier does not wait for the LDS-DMA,
+// 2: no barrier, 4: no LDS-DMA pieces, 8: no fragment reads
+#ifndef G3_AB_GW4_ABLATE
+#define G3_AB_GW4_ABLATE 0
+#endif
+// fragment read: buffer B, fragment F <- LDS [stage-and-k-step address + row-block offset]
+#if G3_AB_GW4_ABLATE & 8
+#define GW4_RD(B, F) ""
+#else
+#define GW4_RD(B, F) "ds_read_b128 v[%c[r" #B #F "]:%c[e" #B #F "]], %[ad" #F "] offset:%c[o" #F "]\n\t"
+#endif
+// MFMA (i, j) on buffer B:  a[16 (4 j + i)] += W_i . T_j^T
+#define GW4_MM(I, J) "v_mfma_f32_32x32x16_bf16 a[%c[d" #I #J "]:%c[z" #I #J "]], v[%c[w" #I "]:%c[x" #I "]], v[%c[t" #J "]:%c[u" #J "]], a[%c[d" #I #J "]:%c[z" #I #J "]]\n\t"
+#if G3_AB_GW4_ABLATE & 4
+#define GW4_DMA(Q) ""
+#else
+#define GW4_DMA(Q) "global_load_lds_dwordx4 %[vo" #Q "], %[sb]\n\ts_add_u32 m0, m0, 0x400\n\t"
+#endif
+
+// One k-step: wait for this k-step's fragments (buffer KS & 1), 16 MFMAs; between them the 8 fragment reads of the next k-step (other buffer)
+// when READ, and 8 LDS-DMA pieces when DMA (destinations m0v + 1 KiB q, per-lane source offsets vo[q] from the wave-uniform base sb).
+// BAR: behind the MFMAs wait for all LDS reads and LDS-DMA of this wave and join the workgroup barrier.
+template <int KS, bool READ, bool DMA, bool BAR>
+G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, uint32_t m0v, const char* sb, const uint32_t (&vo)[8]) {
+    constexpr int cur = GW4_FRAG0 + 32 * (KS & 1), nxt = GW4_FRAG0 + 32 * ((KS & 1) ^ 1);
+#define GW4_OPS_MM(I, J) [d##I##J] "n"(16 * (4 * J + I)), [z##I##J] "n"(16 * (4 * J + I) + 15)
+#define GW4_OPS_ALLMM GW4_OPS_MM(0, 0), GW4_OPS_MM(1, 0), GW4_OPS_MM(2, 0), GW4_OPS_MM(3, 0), GW4_OPS_MM(0, 1), GW4_OPS_MM(1, 1), GW4_OPS_MM(2, 1), GW4_OPS_MM(3, 1), \
+                      GW4_OPS_MM(0, 2), GW4_OPS_MM(1, 2), GW4_OPS_MM(2, 2), GW4_OPS_MM(3, 2), GW4_OPS_MM(0, 3), GW4_OPS_MM(1, 3), GW4_OPS_MM(2, 3), GW4_OPS_MM(3, 3)
+#define GW4_OPS_FR [w0] "n"(cur), [x0] "n"(cur + 3), [w1] "n"(cur + 4), [x1] "n"(cur + 7), [w2] "n"(cur + 8), [x2] "n"(cur + 11), [w3] "n"(cur + 12), [x3] "n"(cur + 15), \
+                   [t0] "n"(cur + 16), [u0] "n"(cur + 19), [t1] "n"(cur + 20), [u1] "n"(cur + 23), [t2] "n"(cur + 24), [u2] "n"(cur + 27), [t3] "n"(cur + 28), [u3] "n"(cur + 31)
+// reads: fragment F of the next buffer; F = 0..3 weight row blocks (address adw, + 4 KiB each), 4..7 token row blocks (adt, T tile)
+#define GW4_OPS_RD [rN0] "n"(nxt), [eN0] "n"(nxt + 3), [rN1] "n"(nxt + 4), [eN1] "n"(nxt + 7), [rN2] "n"(nxt + 8), [eN2] "n"(nxt + 11), [rN3] "n"(nxt + 12), [eN3] "n"(nxt + 15), \
+                   [rN4] "n"(nxt + 16), [eN4] "n"(nxt + 19), [rN5] "n"(nxt + 20), [eN5] "n"(nxt + 23), [rN6] "n"(nxt + 24), [eN6] "n"(nxt + 27), [rN7] "n"(nxt + 28), [eN7] "n"(nxt + 31), \
+                   [ad0] "v"(adw), [ad1] "v"(adw), [ad2] "v"(adw), [ad3] "v"(adw), [ad4] "v"(adt), [ad5] "v"(adt), [ad6] "v"(adt), [ad7] "v"(adt), \
+                   [o0] "n"(0), [o1] "n"(4096), [o2] "n"(8192), [o3] "n"(12288), [o4] "n"(GW4_T_OFF), [o5] "n"(GW4_T_OFF + 4096), [o6] "n"(GW4_T_OFF + 8192), \
+                   [o7] "n"(GW4_T_OFF + 12288)
+#define GW4_OPS_DMA [m0v] "s"(m0v), [sb] "s"(sb), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7])
+#if G3_AB_GW4_ABLATE & 2
+#define GW4_BARRIER "s_waitcnt lgkmcnt(0)\n\t"
+#elif G3_AB_GW4_ABLATE & 1
+#define GW4_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
+#else
+#define GW4_BARRIER "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"
+#endif
+    // token fragments of the previous k-step were last read by its MFMAs (j-major order: T_0 first), so they are overwritten first
+    if constexpr (READ && DMA && !BAR)
+        asm volatile("s_mov_b32 m0, %[m0v]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
+                     GW4_MM(0, 2) GW4_DMA(0) GW4_MM(1, 2) GW4_DMA(1) GW4_MM(2, 2) GW4_DMA(2) GW4_MM(3, 2) GW4_DMA(3)
+                     GW4_MM(0, 3) GW4_DMA(4) GW4_MM(1, 3) GW4_DMA(5) GW4_MM(2, 3) GW4_DMA(6) GW4_MM(3, 3) GW4_DMA(7)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_DMA : GW4_OWNED, "memory");
+    else if constexpr (READ && !DMA && !BAR)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD : GW4_OWNED, "memory");
+    else if constexpr (READ && !DMA && BAR)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3) GW4_BARRIER
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD : GW4_OWNED, "memory");
+    else {
+        static_assert(!READ && !DMA && !BAR, "gw4_kstep: combination not laid out");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_MM(1, 0) GW4_MM(2, 0) GW4_MM(3, 0) GW4_MM(0, 1) GW4_MM(1, 1) GW4_MM(2, 1) GW4_MM(3, 1)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR : GW4_OWNED, "memory");
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [stage 2][W tile 256 x 64 | T tile 256 x 64] bf16
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int g = lane >> 5;
+
+    // XCD-aware tile order (as gemm_bf16_nt_pp_kernel)
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + slot;
+    }
+    int tile_m, tile_n;
+    if (p.tile_order_rowmajor) {
+        tile_m = bid / p.tiles_n;
+        tile_n = bid - tile_m * p.tiles_n;
+    } else {
+        constexpr int GM = 4;
+        const int per_group = GM * p.tiles_n;
+        const int grp = bid / per_group;
+        const int within = bid - grp * per_group;
+        const int gm = min(GM, p.tiles_m - grp * GM);
+        tile_n = within / gm;
+        tile_m = grp * GM + (within - tile_n * gm);
+    }
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int wn = wave & 1;   // feature half of the block tile
+    const int wm = wave >> 1;  // token half
+
+    static_for<0, 256>([&](auto rc) { gw4_acc_zero<decltype(rc)::value>(); });
+
+    // ---- LDS-DMA: wave w stages rows [64 w, 64 w + 64) of both tiles, 8 pieces of 8 rows each; lane -> row 8 q + (lane >> 3), physical chunk
+    // lane & 7 holding logical chunk (lane & 7) ^ ((row >> 1) & 7). Per-lane byte offsets from the tile's first row, rows clamped to the matrix.
+    uint32_t vo_w[8], vo_t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = wave * 64 + 8 * q + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int nrow = min(n0 + r, p.N - 1) - n0, mrow = min(m0 + r, p.M - 1) - m0;  // may be negative only if the tile is empty (never launched)
+        vo_w[q] = (uint32_t)((int64_t)nrow * p.ldw * 2 + chunk * 16);
+        vo_t[q] = (uint32_t)((int64_t)mrow * p.lda * 2 + chunk * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(vo_w[q]), "+v"(vo_t[q]));  // keep them resident
+    const char* w_tile = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    const char* t_tile = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const uint32_t m0_w = lds0 + (uint32_t)wave * 8192u, m0_t = lds0 + GW4_T_OFF + (uint32_t)wave * 8192u;  // + stage * 64 KiB
+
+    // ---- fragment read addresses (stage 0, row block 0): row * 128 + ((2 ks + g) ^ ((row >> 1) & 7)) * 16 = address(ks = 0) ^ (ks << 5)
+    // one set per stage: a ds_read immediate offset has 16 bits and the second stage starts at 64 KiB
+    uint32_t adw[2][4], adt[2][4];
+    {
+        const uint32_t c0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                adw[st][ks] = ((lds0 + (uint32_t)((wn * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
+                adt[st][ks] = ((lds0 + (uint32_t)((wm * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
+            }
+    }
+    if (lds0 & 127u) __builtin_trap();  // the XOR form needs the tiles 128-byte aligned (they are: no static LDS in this kernel)
+
+    const int nk = p.K / BK;
+    // ---- prologue: tile 0 complete and the weight rows of tile 1 in flight; the first fragments of tile 0 into buffer 0
+    {
+        auto dma8 = [&](const char* base, const uint32_t (&vo)[8], uint32_t dst) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + vo[q]),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 1024u * q), 16, 0, 0);
+        };
+        dma8(w_tile, vo_w, m0_w);
+        dma8(t_tile, vo_t, m0_t);
+        dma8(w_tile + 128, vo_w, m0_w + GW4_STAGE_BYTES);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        asm volatile("ds_read_b128 v[192:195], %0\n\tds_read_b128 v[196:199], %0 offset:4096\n\tds_read_b128 v[200:203], %0 offset:8192\n\t"
+                     "ds_read_b128 v[204:207], %0 offset:12288\n\tds_read_b128 v[208:211], %1 offset:32768\n\tds_read_b128 v[212:215], %1 offset:36864\n\t"
+                     "ds_read_b128 v[216:219], %1 offset:40960\n\tds_read_b128 v[220:223], %1 offset:45056"
+                     ::"v"(adw[0][0]), "v"(adt[0][0]) : GW4_OWNED, "memory");
+    }
+
+    // K tile t in stage S = t & 1. DMA_A: token rows of tile t + 1 -> other stage (k-step 0); DMA_W: weight rows of tile t + 2 -> this stage
+    // (k-step 3, behind the barrier); NEXT: prefetch the first fragments of tile t + 1 in k-step 3.
+    auto ktile = [&](auto sc, auto dma_a_c, auto dma_w_c, auto next_c, int t) {
+        constexpr int S = decltype(sc)::value;
+        constexpr bool DMA_A = decltype(dma_a_c)::value, DMA_W = decltype(dma_w_c)::value, NEXT = decltype(next_c)::value;
+        constexpr int SO = S * GW4_STAGE_BYTES, SN = (S ^ 1) * GW4_STAGE_BYTES;
+        G3_JITTER(wave + blockIdx.x, t);
+        gw4_kstep<0, true, DMA_A, false>(adw[S][1], adt[S][1], m0_t + SN, t_tile + (int64_t)(t + 1) * 128, vo_t);
+        gw4_kstep<1, true, false, false>(adw[S][2], adt[S][2], 0u, nullptr, vo_t);
+        if constexpr (NEXT) {
+            gw4_kstep<2, true, false, true>(adw[S][3], adt[S][3], 0u, nullptr, vo_t);
+            gw4_kstep<3, true, DMA_W, false>(adw[S ^ 1][0], adt[S ^ 1][0], m0_w + SO, w_tile + (int64_t)(t + 2) * 128, vo_w);
+        } else {
+            gw4_kstep<2, true, false, false>(adw[S][3], adt[S][3], 0u, nullptr, vo_t);
+            gw4_kstep<3, false, false, false>(0u, 0u, 0u, nullptr, vo_t);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 3 < nk; t += 2) {
+        ktile(S0{}, T_{}, T_{}, T_{}, t);
+        ktile(S1{}, T_{}, T_{}, T_{}, t + 1);
+    }
+    if (nk - t == 3) {
+        ktile(S0{}, T_{}, T_{}, T_{}, t);
+        ktile(S1{}, T_{}, F_{}, T_{}, t + 1);
+        ktile(S0{}, F_{}, F_{}, F_{}, t + 2);
+    } else {  // 2 tiles left
+        ktile(S0{}, T_{}, F_{}, T_{}, t);
+        ktile(S1{}, F_{}, F_{}, F_{}, t + 1);
+    }
+
+    // ---- epilogue: the accumulators leave the AGPRs one 64-token half at a time and go through the full-line LDS transpose of the other
+    // kernels (private 16 KiB slice per wave; the operand stages are idle once every wave is past its last fragment read)
+    asm volatile("s_nop 7\n\ts_nop 3" ::: GW4_OWNED);  // last MFMA results -> v_accvgpr_read
+    __syncthreads();
+    static_for<0, 2>([&](auto jhc) {
+        constexpr int jh = decltype(jhc)::value;
+        f32x16 acc[4][2];
+        static_for<0, 128>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;  // register 16 (4 jj + i) + r of this half
+            constexpr int blk = R >> 4, r = R & 15, i = blk & 3, jj = blk >> 2;
+            acc[i][jj][r] = gw4_acc_read<128 * jh + R>();
+        });
+        store_tile_lds<EPI>(p, acc, m0 + wm * 128 + 64 * jh, n0 + wn * 128, lane, smem_raw + wave * 16384);
+    });
+}
+
+template <int EPI>
+int launch_w4(const GemmParams& p, hipStream_t stream, const char* what) {
+    const size_t smem = 2 * GW4_STAGE_BYTES;
+    static bool attr_set[64] = {};
+    static std::mutex attr_mu;
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipGetDevice failed");
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (!attr_set[dev_id]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set[dev_id] = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(GW4_THREADS), smem, stream, p);
+    return g3_check_launch(what);
+}

@@ -36,7 +36,7 @@ def test_gemm_pingpong_bitwise_equals_classic_and_is_race_free():
         res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
         kw = dict(gate=gate, residual=res) if epi == 2 else (dict(gate=gate) if epi == 3 else {})
         outs = {}
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):  # 3 = one wave per SIMD (gemm_w4.hpp); falls back to 2 where it does not apply (K < 128)
             ops.set_option("gemm_pingpong", variant)
             first = ops.gemm_nt(a, w, epilogue=epi, **kw).clone()
             for _ in range(8):
@@ -44,7 +44,7 @@ def test_gemm_pingpong_bitwise_equals_classic_and_is_race_free():
                 assert torch.equal(first, again), f"variant {variant} not reproducible at {M}x{N}x{K}"
             outs[variant] = first
         ops.set_option("gemm_pingpong", 2)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"ping-pong != classic at {M}x{N}x{K} epi {epi}"
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]), f"ping-pong / w4 != classic at {M}x{N}x{K} epi {epi}"
 
 
 def _report(name, got, ref):
@@ -55,7 +55,7 @@ def _report(name, got, ref):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 260, 136), (1000, 64, 328), (56, 1024, 4096),
                                    (2048, 4096, 1024), (300, 520, 128), (257, 264, 192), (640, 256, 320)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("regstage", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("regstage", [0, 1, 2, 3, 4, 5])
 def test_gemm_nt(M, N, K, epi, regstage):
     from gen3c_amd import ops
     dev = _dev()
@@ -64,10 +64,12 @@ def test_gemm_nt(M, N, K, epi, regstage):
         pytest.skip("K % 64 != 0 always takes the register-staged path")
     # 4 = the default kernel with the direct 8-byte-per-lane epilogue instead of the LDS-transposed full-line one
     ops.set_option("gemm_wide_store", 0 if regstage == 4 else 1)
+    # 5 = the one-wave-per-SIMD kernel (gemm_w4.hpp; K >= 128, else the ping-pong kernel runs)
+    label = regstage
     if regstage == 4:
         regstage = 3
     ops.set_option("gemm_regstage", 1 if regstage == 1 else 0)
-    ops.set_option("gemm_pingpong", regstage - 1 if regstage >= 2 else 0)
+    ops.set_option("gemm_pingpong", 3 if regstage == 5 else (regstage - 1 if regstage >= 2 else 0))
     g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K + epi)
     a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
@@ -89,7 +91,7 @@ def test_gemm_nt(M, N, K, epi, regstage):
     ops.set_option("gemm_regstage", 0)
     ops.set_option("gemm_pingpong", 2)
     ops.set_option("gemm_wide_store", 1)
-    _report(f"gemm {M}x{N}x{K} epi{epi} regstage{regstage}", out, ref)
+    _report(f"gemm {M}x{N}x{K} epi{epi} regstage{label}", out, ref)
     # one bf16 rounding of the output (2^-8 relative worst case) + fp32 accumulation noise
     torch.testing.assert_close(out.float(), ref, rtol=1.0 / 128, atol=2e-2)
     assert _rel_l2(out, ref) < 4e-3

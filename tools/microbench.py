@@ -34,7 +34,7 @@ def bench_gemm():
         fl = 2.0 * M * N * K
         res_line = []
         for rnd in range(2):
-            for variant in (1, 2):
+            for variant in (2, 3):
                 ops.set_option("gemm_pingpong", variant)
                 ms = timeit(lambda: ops.gemm_nt(a, w, out=out, epilogue=epi, **kw), 5)
                 res_line.append((variant, ms, fl / ms / 1e9))

@@ -82,7 +82,7 @@ for (M, N, K, epi) in [(56320, 4096, 4096, 2), (7040, 12288, 4096, 0), (4096, 16
     w_ = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
     gate = torch.randn(1, N, device=dev, generator=g).to(torch.bfloat16)
     res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
-    for pp in (0, 1, 2):
+    for pp in (0, 1, 2, 3):
         def run(lib):
             lib.g3_set_option(b"gemm_pingpong", pp)
             o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
