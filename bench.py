@@ -234,7 +234,7 @@ def main():
     if gemms:
         g_ms = sum(ms for _, ms in gemms)
         g_fl = sum(2.0 * m["M"] * m["N"] * m["K"] for m, _ in gemms)
-        roof_gemm = dict(bound="mfma", kernel="gemm_bf16_nt_pp_kernel<EPI,2,false>", achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
+        roof_gemm = dict(bound="mfma", kernel="gemm_bf16_nt_w4_kernel<EPI>", achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
                          unit="TFLOP/s", frac=round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), launches=len(gemms),
                          total_ms_per_step=round(g_ms / args.steps, 2))
 

@@ -32,7 +32,7 @@ int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 0);  // 0 = automatic (atte
 int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 int g3_opt_gemm_wide_store = env_int("G3_GEMM_WIDE_STORE", 1);
 int g3_opt_splat_tiled = env_int("G3_SPLAT_TILED", 1);
-int g3_opt_gemm_pingpong = env_int("G3_GEMM_PINGPONG", 2);
+int g3_opt_gemm_pingpong = env_int("G3_GEMM_PINGPONG", 3);  // 3: one wave per SIMD (gemm_w4.hpp) where it applies, else the 2-phase ping-pong kernel
 int g3_opt_gemm_unpinned = env_int("G3_GEMM_UNPINNED", 1);  // measured: pinning the LDS prefetch does not help this kernel (profiles/r1_v4_gemm_pin_ab.txt)
 
 extern "C" int g3_set_option(const char* name, int value) {

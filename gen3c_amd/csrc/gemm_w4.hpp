@@ -214,6 +214,23 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
             gw4_kstep<3, false, false, false>(0u, 0u, 0u, nullptr, vo_t);
         }
     };
+    // residual rows of the epilogue (EPI_GATED_RESIDUAL / EPI_BIAS_RESIDUAL), in the epilogue's read-back layout: block J (32 tokens), pass s8:
+    // token row 32 J + 4 s8 + (lane >> 4), features 8 (lane & 15) .. + 7. Requested before the LAST K tile: 128 VGPRs that are idle until then.
+    constexpr bool HAS_RES = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS_RESIDUAL);
+    const int rsub = lane >> 4, c2 = lane & 15;
+    bf16x8 rpre[HAS_RES ? 4 : 1][HAS_RES ? 8 : 1];
+    auto prefetch_residual = [&]() {
+        if constexpr (HAS_RES) {
+            const int n = n0 + wn * 128 + 8 * c2;
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const int m = m0 + wm * 128 + 32 * J + 4 * s8 + rsub;
+                    rpre[J][s8] = (m < p.M && n < p.N) ? load_bf16x8(p.R + (int64_t)m * p.ldr + n) : zero_bf16x8();
+                }
+        }
+    };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
     using S0 = std::integral_constant<int, 0>;
@@ -226,26 +243,76 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     if (nk - t == 3) {
         ktile(S0{}, T_{}, T_{}, T_{}, t);
         ktile(S1{}, T_{}, F_{}, T_{}, t + 1);
+        prefetch_residual();
         ktile(S0{}, F_{}, F_{}, F_{}, t + 2);
     } else {  // 2 tiles left
         ktile(S0{}, T_{}, F_{}, T_{}, t);
+        prefetch_residual();
         ktile(S1{}, F_{}, F_{}, F_{}, t + 1);
     }
 
-    // ---- epilogue: the accumulators leave the AGPRs one 64-token half at a time and go through the full-line LDS transpose of the other
-    // kernels (private 16 KiB slice per wave; the operand stages are idle once every wave is past its last fragment read)
+    // ---- epilogue: the accumulators leave the AGPRs one 32-token block (64 registers) at a time and go through the full-line LDS transpose of
+    // the other kernels (store_tile_lds: private 16 KiB fp32 slice per wave, a lane then owns 8 consecutive features of one token row). At one
+    // wave per SIMD nothing covers the latency of the residual rows, so they were requested before the last K tile (rpre).
     asm volatile("s_nop 7\n\ts_nop 3" ::: GW4_OWNED);  // last MFMA results -> v_accvgpr_read
-    __syncthreads();
-    static_for<0, 2>([&](auto jhc) {
-        constexpr int jh = decltype(jhc)::value;
-        f32x16 acc[4][2];
-        static_for<0, 128>([&](auto rc) {
-            constexpr int R = decltype(rc)::value;  // register 16 (4 jj + i) + r of this half
-            constexpr int blk = R >> 4, r = R & 15, i = blk & 3, jj = blk >> 2;
-            acc[i][jj][r] = gw4_acc_read<128 * jh + R>();
+    __syncthreads();                                     // the operand stages are idle once every wave is past its last fragment read
+    {
+        char* stage = smem_raw + wave * 16384;
+        const int n = n0 + wn * 128 + 8 * c2;
+        bf16x8 gv1 = zero_bf16x8();
+        if (EPI != EPI_NONE && EPI != EPI_GELU && p.gate_rows == 1 && n < p.N) gv1 = load_bf16x8(p.gate + n);
+        static_for<0, 4>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            f32x16 acc[4];
+            static_for<0, 64>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                acc[R >> 4][R & 15] = gw4_acc_read<64 * J + R>();
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * q4 + e];
+                    *reinterpret_cast<f32x4*>(stage + l31 * 512 + (((8 * i + 2 * q4 + g) ^ l31) << 4)) = v;
+                }
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int row = 4 * s8 + rsub;
+                const int m = m0 + wm * 128 + 32 * J + row;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 512 + (((2 * c2) ^ row) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * 512 + (((2 * c2 + 1) ^ row) << 4));
+                if (m >= p.M || n >= p.N) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = lo[e];
+                    v[4 + e] = hi[e];
+                }
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+                } else if (EPI != EPI_NONE) {
+                    const bf16x8 gv = p.gate_rows == 1 ? gv1 : load_bf16x8(p.gate + (int64_t)(m % p.gate_rows) * p.ldg + n);
+                    if (EPI == EPI_GATED_RESIDUAL) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)rpre[J][s8][e] + (float)gv[e] * v[e];
+                    } else if (EPI == EPI_BIAS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)gv[e];
+                    } else if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (v[e] + (float)gv[e]) + (float)rpre[J][s8][e];
+                    }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
+                store_bf16x8(p.C + (int64_t)m * p.ldc + n, o);
+            }
         });
-        store_tile_lds<EPI>(p, acc, m0 + wm * 128 + 64 * jh, n0 + wn * 128, lane, smem_raw + wave * 16384);
-    });
+    }
 }
 
 template <int EPI>

@@ -43,7 +43,7 @@ def test_gemm_pingpong_bitwise_equals_classic_and_is_race_free():
                 again = ops.gemm_nt(a, w, epilogue=epi, **kw)
                 assert torch.equal(first, again), f"variant {variant} not reproducible at {M}x{N}x{K}"
             outs[variant] = first
-        ops.set_option("gemm_pingpong", 2)
+        ops.set_option("gemm_pingpong", 3)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]), f"ping-pong / w4 != classic at {M}x{N}x{K} epi {epi}"
 
 
@@ -89,7 +89,7 @@ def test_gemm_nt(M, N, K, epi, regstage):
         out = ops.gemm_nt(a, w)
     torch.cuda.synchronize()
     ops.set_option("gemm_regstage", 0)
-    ops.set_option("gemm_pingpong", 2)
+    ops.set_option("gemm_pingpong", 3)
     ops.set_option("gemm_wide_store", 1)
     _report(f"gemm {M}x{N}x{K} epi{epi} regstage{label}", out, ref)
     # one bf16 rounding of the output (2^-8 relative worst case) + fp32 accumulation noise

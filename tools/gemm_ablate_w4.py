@@ -48,4 +48,4 @@ for (nm, M, N, K, epi) in [("qkv", 56320, 12288, 4096, 0), ("out", 56320, 4096, 
             line.append(f"[{label} {ms:.3f}ms {fl / ms / 1e9:.0f}TF]")
         print(f"gemm {nm} {M}x{N}x{K} epi{epi}: " + "  ".join(line), flush=True)
     del a, w, gate, res, out
-_lib.load().g3_set_option(b"gemm_pingpong", 2)
+_lib.load().g3_set_option(b"gemm_pingpong", 3)

@@ -38,7 +38,7 @@ def bench_gemm():
                 ops.set_option("gemm_pingpong", variant)
                 ms = timeit(lambda: ops.gemm_nt(a, w, out=out, epilogue=epi, **kw), 5)
                 res_line.append((variant, ms, fl / ms / 1e9))
-        ops.set_option("gemm_pingpong", 2)
+        ops.set_option("gemm_pingpong", 3)
         if epi == 0:  # vendor-library yardstick for the plain GEMM (hipBLASLt through torch; not part of the product path)
             wt = w.t()
             ms = timeit(lambda: torch.matmul(a, wt, out=out), 5)

@@ -117,6 +117,6 @@ for (C_in, C_out, T, Hh, Ww, kt, kh, kw, st_, sh, sw) in [(128, 256, 5, 48, 64, 
         report(f"conv {C_in}->{C_out} k=({kt},{kh},{kw}) s=({st_},{sh},{sw}) on {T}x{Hh}x{Ww} pingpong={pp}", x, y)
 for lib in (base, alt):
     lib.g3_set_option(b"attn_variant", 0)
-    lib.g3_set_option(b"gemm_pingpong", 2)
+    lib.g3_set_option(b"gemm_pingpong", 3)
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
 sys.exit(1 if bad else 0)
