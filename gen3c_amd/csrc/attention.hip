@@ -889,9 +889,9 @@ static int attn_resolve_variant(int Sq, int Skv, int B, int H) {
         const long n_wg = (long)((Sq + 255) / 256) * H * B;
         const long rounds = (n_wg + 255) / 256;
         const bool even_fill = n_wg * 100 >= rounds * 256 * 93;  // <= 7 % of the last round idle (one workgroup per CU)
-        variant = (Skv > 2048 && (Skv % KVB) == 0 && even_fill) ? 10 : 4;
+        variant = (Skv > 2048 && (Skv % KVB) == 0 && even_fill) ? 11 : 4;
     }
-    if (variant == 10 && (Skv % KVB)) variant = 9;  // w4b: whole 64-key tiles only
+    if ((variant == 10 || variant == 11) && (Skv % KVB)) variant = 9;  // w4b: whole 64-key tiles only
     return variant;
 }
 
@@ -906,7 +906,8 @@ extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) 
         case 7: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>" : "flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>";
         case 8: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, false, true>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false, true>";
         case 9: return long_ctx ? "flash_attn_fwd_w4_kernel<0>" : "flash_attn_fwd_w4_kernel<1>";
-        case 10: return "flash_attn_fwd_w4b_kernel";
+        case 10: return "flash_attn_fwd_w4b_kernel<false>";
+        case 11: return "flash_attn_fwd_w4b_kernel<true>";
         default: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, true>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false>";
     }
 }
@@ -938,9 +939,9 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
-    // 0 (default) = automatic: w4b (10) on long contexts made of whole 64-key tiles whose 256-row workgroups fill the chip's 256 CUs evenly,
+    // 0 (default) = automatic: w4b with the cross-barrier prefetch (11) on long contexts made of whole 64-key tiles whose 256-row workgroups fill the chip's 256 CUs evenly,
     // else 4. Explicit values are kept for A/B runs and tests: 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave,
-    // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b.
+    // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b, 11 = w4b + cross-barrier prefetch.
     int variant = attn_resolve_variant(Sq, Skv, B, H);
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
@@ -964,7 +965,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     {
       std::lock_guard<std::mutex> attr_lock(attr_mu);
       if (!attr_set[dev_id]) {
-        const void* fns[15] = {reinterpret_cast<const void*>(&flash_attn_fwd_w4b_kernel),
+        const void* fns[16] = {reinterpret_cast<const void*>(&flash_attn_fwd_w4b_kernel<false>), reinterpret_cast<const void*>(&flash_attn_fwd_w4b_kernel<true>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_v2_kernel<1>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false>),
@@ -972,7 +973,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, true, true, 4, 4>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, true, true, 4, 4>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<0, 6, 8, false, true>), reinterpret_cast<const void*>(&flash_attn_fwd_v3_kernel<1, 6, 8, false, true>),
                                reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<0>), reinterpret_cast<const void*>(&flash_attn_fwd_w4_kernel<1>)};
-        for (int i = 0; i < 15; ++i) {
+        for (int i = 0; i < 16; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
@@ -982,9 +983,10 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     dim3 grid((Sq + BQ - 1) / BQ, H, B);
     const bool long_ctx = Skv > 2048;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 10) {  // w4 with the trimmed issue stream (attention_w4b.hpp)
+    if (variant == 10 || variant == 11) {  // w4 with the trimmed issue stream (attention_w4b.hpp)
         dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
-        hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel, grid4, dim3(W4_THREADS), smem, st, p);
+        if (variant == 11) hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel<true>, grid4, dim3(W4_THREADS), smem, st, p);
+        else hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel<false>, grid4, dim3(W4_THREADS), smem, st, p);
         return g3_check_launch("g3_flash_attn_fwd_bf16");
     }
     if (variant == 9) {  // one wave per SIMD, 64 query rows per wave (attention_w4.hpp)

@@ -56,9 +56,14 @@ template <int O0, int O1, int O2, int O3, int O4, int O5> G3_DEVICE void w4b_rea
 }
 
 // ---- region A step I: [m0] [read] wait ; S0 (+)= K.Q0 ; pair unit ; [LDS-DMA piece] ; S1 (+)= K.Q1
-template <int I, int ROFF, bool READ, int WN, bool INIT, bool DMA>
+// EXTRA (steps without INIT / DMA only): half of a second pair unit behind the step - 1: exp2, exp2, first row-sum add; 2 (two steps later, so
+// that no statement reads what its predecessor wrote): second add + cvt_pk
+#define W4B_XA "v_exp_f32 %[a2], %[x2]\n\tv_exp_f32 %[b2], %[y2]\n\tv_add_f32 %[pe], %[pe], %[a2]\n\t"
+#define W4B_XB "v_add_f32 %[pe], %[pe], %[b2]\n\tv_cvt_pk_bf16_f32 %[k2], %[a2], %[b2]\n\t"
+template <int I, int ROFF, bool READ, int WN, bool INIT, bool DMA, int EXTRA = 0>
 G3_DEVICE void w4b_step_qk(uint32_t addr, f32x16& s0, f32x16& s1, const f32x16& c0, const f32x16& c1, float x1, float y1, uint32_t& k1, float& p1, float& r1,
-                           uint32_t m0v, uint32_t voff, const char* sbase, float& a1, float& b1) {
+                           uint32_t m0v, uint32_t voff, const char* sbase, float& a1, float& b1, float x2 = 0.f, float y2 = 0.f, uint32_t* k2 = nullptr,
+                           float* pe = nullptr, float* a2 = nullptr, float* b2 = nullptr) {
     constexpr int ks = I >> 1;
     constexpr int q0 = W4_QBASE + 4 * ks, q1 = W4_QBASE + 4 * (8 + ks);
     constexpr int fa = W4B_RING0 + 4 * (I & 15), ra = W4B_RING0 + 4 * ((I + W4B_D) & 15);
@@ -76,8 +81,15 @@ G3_DEVICE void w4b_step_qk(uint32_t addr, f32x16& s0, f32x16& s1, const f32x16& 
     else if constexpr (INIT && !DMA)
         asm volatile(W4B_READ W4_WAIT W4B_QK0(0) W4_UNIT(1) W4B_QK0(1)
                      : W4B_A_OUT, [s0] "=&v"(s0), [s1] "=&v"(s1) : W4B_A_IN, [c0] "v"(c0), [c1] "v"(c1));
+    else if constexpr (EXTRA == 1)
+        asm volatile(W4B_READ W4_WAIT W4B_QK(0) W4_UNIT(1) W4B_QK(1) W4B_XA
+                     : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1), [a2] "=&v"(*a2), [b2] "=&v"(*b2), [pe] "+v"(*pe) : W4B_A_IN, [x2] "v"(x2), [y2] "v"(y2));
+    else if constexpr (EXTRA == 2)
+        asm volatile(W4B_READ W4_WAIT W4B_QK(0) W4_UNIT(1) W4B_QK(1) W4B_XB
+                     : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1), [k2] "=&v"(*k2), [pe] "+v"(*pe) : W4B_A_IN, [a2] "v"(*a2), [b2] "v"(*b2));
     else
         asm volatile(W4B_READ W4_WAIT W4B_QK(0) W4_UNIT(1) W4B_QK(1) : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1) : W4B_A_IN);
+    static_assert(EXTRA == 0 || (!INIT && !DMA), "w4b_step_qk: extra half units only on plain steps");
 #undef W4B_A_OUT
 #undef W4B_A_IN
 }
@@ -112,6 +124,10 @@ G3_DEVICE void w4b_step_pv(uint32_t addr, const u32x4& pf0, const u32x4& pf1, fl
         asm volatile(W4_WAIT W4B_PV(0) W4B_MAXP(0) W4B_PV(1) W4B_MAXP(1) W4B_MAXP(2)
                      : [mx] "+v"(mx), [my] "+v"(my)
                      : W4B_B_IN, W4B_B_M0, [ma1] "v"(ma1), [mb1] "v"(mb1), [mc1] "v"(mc1), [md1] "v"(md1), [ma2] "v"(ma2), [mb2] "v"(mb2), [mc2] "v"(mc2), [md2] "v"(md2));
+    else if constexpr (READ && !UNIT && MX == 3)
+        asm volatile(W4B_READ W4_WAIT W4B_PV(0) W4B_MAXP(0) W4B_PV(1) W4B_MAXP(1) W4B_MAXP(2)
+                     : [mx] "+v"(mx), [my] "+v"(my)
+                     : W4B_B_IN, W4B_B_RD, W4B_B_M0, [ma1] "v"(ma1), [mb1] "v"(mb1), [mc1] "v"(mc1), [md1] "v"(md1), [ma2] "v"(ma2), [mb2] "v"(mb2), [mc2] "v"(mc2), [md2] "v"(md2));
     else if constexpr (READ && !UNIT && MX == 0)
         asm volatile(W4B_READ W4_WAIT W4B_PV(0) W4B_PV(1) : : W4B_B_IN, W4B_B_RD);
     else {
@@ -126,13 +142,22 @@ G3_DEVICE void w4b_step_pv(uint32_t addr, const u32x4& pf0, const u32x4& pf1, fl
 // region B steps 14 / 15: the four chains of each half are folded and exchanged with lane ^ 32
 // step 14: wait ; PV0 ; a_h = max3(a_h, b_h, c_h), a_h = max(a_h, d_h) (h = 0, 1) ; PV1 ; t_h = a_h
 // step 15: wait ; PV0 ; swap upper half of t_h with lower half of a_h ; PV1 ; a_h = max(a_h, t_h)
-template <int I, int WN>
+template <int I, int WN, bool READ = false, int ROFF = 0>
 G3_DEVICE void w4b_step_pv_fold(const u32x4& pf0, const u32x4& pf1, float& a0, float& b0, float& c0, float& d0, float& a1, float& b1, float& c1, float& d1, float& t0,
-                                 float& t1) {
+                                 float& t1, uint32_t addr = 0u) {
     constexpr int D = I & 3;
     constexpr int o0 = 16 * D, o1 = 16 * (4 + D);
-    constexpr int fa = W4B_RING0 + 4 * ((16 + I) & 15);
-    if constexpr (I == 14)
+    constexpr int fa = W4B_RING0 + 4 * ((16 + I) & 15), ra = W4B_RING0 + 4 * ((16 + I + W4B_D) & 15);
+    if constexpr (READ && I == 14)
+        asm volatile(W4B_READ W4_WAIT W4B_PV(0) "v_max3_f32 %[a0], %[a0], %[b0], %[c0]\n\tv_max3_f32 %[a1], %[a1], %[b1], %[c1]\n\tv_max_f32 %[a0], %[a0], %[d0]\n\tv_max_f32 %[a1], %[a1], %[d1]\n\t"
+                     W4B_PV(1) "v_mov_b32 %[t0], %[a0]\n\tv_mov_b32 %[t1], %[a1]\n\t"
+                     : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                     : W4B_B_IN, [b0] "v"(b0), [c0] "v"(c0), [d0] "v"(d0), [b1] "v"(b1), [c1] "v"(c1), [d1] "v"(d1), [addr] "v"(addr), [off] "n"(ROFF), [ra] "n"(ra), [rb] "n"(ra + 3));
+    else if constexpr (READ)
+        asm volatile(W4B_READ W4_WAIT W4B_PV(0) "v_permlane32_swap_b32 %[t0], %[a0]\n\tv_permlane32_swap_b32 %[t1], %[a1]\n\t" W4B_PV(1)
+                     "v_max_f32 %[a0], %[a0], %[t0]\n\tv_max_f32 %[a1], %[a1], %[t1]\n\t"
+                     : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "+v"(t0), [t1] "+v"(t1) : W4B_B_IN, [addr] "v"(addr), [off] "n"(ROFF), [ra] "n"(ra), [rb] "n"(ra + 3));
+    else if constexpr (I == 14)
         asm volatile(W4_WAIT W4B_PV(0) "v_max3_f32 %[a0], %[a0], %[b0], %[c0]\n\tv_max3_f32 %[a1], %[a1], %[b1], %[c1]\n\tv_max_f32 %[a0], %[a0], %[d0]\n\tv_max_f32 %[a1], %[a1], %[d1]\n\t"
                      W4B_PV(1) "v_mov_b32 %[t0], %[a0]\n\tv_mov_b32 %[t1], %[a1]\n\t"
                      : [a0] "+v"(a0), [a1] "+v"(a1), [t0] "=&v"(t0), [t1] "=&v"(t1)
@@ -158,6 +183,9 @@ template <int R> G3_DEVICE void w4b_set_inplace(f32x16& x, float v) {
 }
 G3_DEVICE void w4b_mul_inplace(float& x, float a) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a)); }
 
+// XB: the tile barrier sits in the P.V region (before step 10) and steps 10..15 read the NEXT tile's first six K fragments across it, so a tile
+// starts with its operands in the ring; the four pair units that covered the head reads move into region A as half units.
+template <bool XB>
 __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);  // [2][64][128]
@@ -240,6 +268,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
 #pragma unroll
         for (int k = 0; k < 4; ++k) psum[h][k] = 0.f;
     float ta[2] = {0.f, 0.f}, tb[2] = {0.f, 0.f};  // exp2 results of a pair unit, one set per step parity (see the note on statement boundaries)
+    float pe[2][2] = {{0.f, 0.f}, {0.f, 0.f}};     // XB: row-sum accumulators of the half units (half 0; [step parity][lane of the pair])
+    float xa[2], xb[2];                            // XB: exp2 results of a half unit between its two steps
     const int nt = p.Skv / KVB;                     // launcher: S_kv % 64 == 0
 
     // ---- prologue: K(0), V(0) (and K(1)) by LDS-DMA; scores of tile 0 with C = 0, then made relative to their exact row maximum
@@ -287,6 +317,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
         for (int r = 0; r < 16; ++r) negm[h][r] = -m_run[h];
         mx_cur[h] = 0.f;
     }
+    if (XB && nt > 1) {  // the first six K(1) fragments (slot 1 of the K ring, published by the prologue barrier): tile 0 starts with them in the ring
+        constexpr int KS1 = KVB * HD * 2;
+        w4b_read_head<KS1, KS1 + 32 * HD * 2, KS1, KS1 + 32 * HD * 2, KS1, KS1 + 32 * HD * 2>(kaddr[0], kaddr[1], kaddr[2]);
+    }
     // wave-uniform source state of the in-stream LDS-DMA: V^T tile t+1 (byte offset inside a row, tiles left in its segment)
     uint32_t v_off_next = v_tile_off(KVB);
     const uint32_t seg_tiles = seg_len ? seg_len / KVB : 0x7fffffffu;
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
         auto frag_addr = [&](auto nc) -> uint32_t { constexpr int n = decltype(nc)::value; if constexpr (n < 16) return kaddr[(n >> 1) & 7]; else return vaddr[((n - 16) >> 2) & 3]; };
         G3_JITTER(wave + blockIdx.x, t);  // race screen only
         // ---- tile head: the first D fragment reads; their latency is covered by the rescale test and four pair units
-        {
+        if constexpr (!(XB && has_next)) {
             constexpr int n0 = has_next ? 0 : 16;
             using N0 = std::integral_constant<int, n0>;
             using N1 = std::integral_constant<int, n0 + 1>;
@@ -330,6 +364,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w4b_mul_inplace(psum[h][k], alpha[h]);
+                if (XB && h == 0) {
+                    w4b_mul_inplace(pe[0][0], alpha[0]);
+                    w4b_mul_inplace(pe[0][1], alpha[0]);
+                    w4b_mul_inplace(pe[1][0], alpha[0]);
+                    w4b_mul_inplace(pe[1][1], alpha[0]);
+                }
                 const float nm = -m_run[h], dl = delta[h];
                 static_for<0, 16>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
@@ -358,7 +398,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
             }
             uput(uc, pk);
         };
-        constexpr int NHEAD = has_next ? 4 : 20;  // pair units at the tile head (the last tile has no region A to carry units 4..19)
+        constexpr int NHEAD = has_next ? (XB ? 0 : 4) : 20;  // pair units at the tile head (the last tile has no region A to carry units 4..19)
         static_for<0, NHEAD>([&](auto uc) { sm_unit(uc); });
 
         // ---- region A: S_next[h] = K(t+1).Q_h^T, step I: key block mb = I & 1, k-step ks = I >> 1 (alternating blocks), pair unit 4 + I,
@@ -370,14 +410,26 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
             static_for<0, 16>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 using NR = std::integral_constant<int, I + D>;
-                using U = std::integral_constant<int, 4 + I>;
+                using U = std::integral_constant<int, (XB ? 0 : 4) + I>;
                 constexpr int hu = (U::value >> 2) & 1, pa = 2 * (I & 1);
                 constexpr bool dma = I < 8;
                 constexpr int j = I & 7;
                 const uint32_t m0v = dma ? (j < 4 ? lds_k0 + (uint32_t)(par * KVB * HD * 2 + 256 * j * 16) : lds_v0 + (uint32_t)((par ^ 1) * HD * KVB * 2 + 256 * (j - 4) * 16)) + (uint32_t)wave * 1024u : 0u;
                 uint32_t k1 = 0;
-                w4b_step_qk<I, frag_off(NR{}), true, D, (I >> 1) == 0, dma>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
-                                                                           psum[hu][pa], psum[hu][pa + 1], m0v, dma_off[j], j < 4 ? kbase : vbase, ta[I & 1], tb[I & 1]);
+                if constexpr (XB && I >= 8) {
+                    // half units of pair units 16..19 (all half 0): steps 8, 9 / 12, 13 first halves, steps 10, 11 / 14, 15 second halves
+                    constexpr int ex = (I & 2) ? 2 : 1;
+                    constexpr int xu = 16 + ((I - 8) >> 2) * 2 + (I & 1);
+                    using XU = std::integral_constant<int, xu>;
+                    uint32_t k2 = 0;
+                    w4b_step_qk<I, frag_off(NR{}), true, D, false, false, ex>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
+                                                                              psum[hu][pa], psum[hu][pa + 1], 0u, 0u, nullptr, ta[I & 1], tb[I & 1], ux(XU{}), uy(XU{}), &k2,
+                                                                              &pe[I & 1][ex - 1], &xa[I & 1], &xb[I & 1]);
+                    if constexpr (ex == 2) uput(XU{}, k2);
+                } else {
+                    w4b_step_qk<I, frag_off(NR{}), true, D, (I >> 1) == 0, dma>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
+                                                                               psum[hu][pa], psum[hu][pa + 1], m0v, dma_off[j], j < 4 ? kbase : vbase, ta[I & 1], tb[I & 1]);
+                }
                 uput(U{}, k1);
             });
             // V^T source of the next tile's pieces
@@ -391,9 +443,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
         {
             float cx[2][2], cy[2][2], tx[2];  // chains [half][step parity] of key block 0 / 1, exchange temporaries
             auto sn = [&](auto hc, auto mbc, auto rc) -> float { return S_next[decltype(hc)::value][decltype(mbc)::value][decltype(rc)::value]; };
+            // XB: fragment n >= 32 is fragment n - 32 of the NEXT tile: K(t+2), published by the barrier in front of step 10, slot `par` of the K ring
+            constexpr int KSN = par * KVB * HD * 2;
+            auto rd_off = [](auto nc) constexpr { constexpr int n = decltype(nc)::value; return n < 32 ? VS + 32 * ((n - 16) & 3) * KVB * 2 : KSN + 32 * (n & 1) * HD * 2; };
+            auto rd_addr = [&](auto nc) -> uint32_t { constexpr int n = decltype(nc)::value; if constexpr (n < 32) return vaddr[((n - 16) >> 2) & 3]; else return kaddr[((n - 32) >> 1) & 7]; };
             static_for<0, 14>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
-                constexpr bool rd = I + D < 16;
+                constexpr bool rd = (I + D < 16) || (XB && has_next);
                 using NR = std::integral_constant<int, rd ? 16 + I + D : 16>;
                 constexpr bool unit = I < 12;
                 using U = std::integral_constant<int, unit ? 20 + I : 20>;
@@ -406,18 +462,32 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
                 constexpr int k1i = mxk == 3 ? k0 + 1 : k0, k2i = mxk == 3 ? k0 + 2 : k0;
                 using H = std::integral_constant<int, mh>;
 #define W4B_SN(mb, r) (has_next ? sn(H{}, std::integral_constant<int, mb>{}, std::integral_constant<int, (r)>{}) : 0.f)
+                if constexpr (XB && has_next && I == 10) {
+                    // every wave has issued its last read of V^T(t) (step 9) and of K(t+1) (region A): drain this wave's LDS-DMA and publish
+                    // K(t+2) / V^T(t+1). No operands: the statement shares no register with its neighbours (no pad).
+                    if (!(G3_AB_ATTN_ABLATE & 64)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
                 uint32_t k1 = 0;
-                w4b_step_pv<I, frag_off(NR{}), rd, rd ? D : 15 - I, unit, mxk>(frag_addr(NR{}), pb[0][I >> 2], pb[1][I >> 2], ux(U{}), uy(U{}), k1, psum[hu][pa], psum[hu][pa + 1],
-                                                                            cx[mh][I & 1], cy[mh][I & 1], W4B_SN(0, 2 * k0), W4B_SN(0, 2 * k0 + 1), W4B_SN(1, 2 * k0),
-                                                                            W4B_SN(1, 2 * k0 + 1), W4B_SN(0, 2 * k1i), W4B_SN(0, 2 * k1i + 1), W4B_SN(1, 2 * k1i),
-                                                                            W4B_SN(1, 2 * k1i + 1), W4B_SN(0, 2 * k2i), W4B_SN(0, 2 * k2i + 1), W4B_SN(1, 2 * k2i),
-                                                                            W4B_SN(1, 2 * k2i + 1), ta[I & 1], tb[I & 1]);
+                w4b_step_pv<I, rd_off(NR{}), rd, rd ? D : 15 - I, unit, mxk>(rd_addr(NR{}), pb[0][I >> 2], pb[1][I >> 2], ux(U{}), uy(U{}), k1, psum[hu][pa], psum[hu][pa + 1],
+                                                                          cx[mh][I & 1], cy[mh][I & 1], W4B_SN(0, 2 * k0), W4B_SN(0, 2 * k0 + 1), W4B_SN(1, 2 * k0),
+                                                                          W4B_SN(1, 2 * k0 + 1), W4B_SN(0, 2 * k1i), W4B_SN(0, 2 * k1i + 1), W4B_SN(1, 2 * k1i),
+                                                                          W4B_SN(1, 2 * k1i + 1), W4B_SN(0, 2 * k2i), W4B_SN(0, 2 * k2i + 1), W4B_SN(1, 2 * k2i),
+                                                                          W4B_SN(1, 2 * k2i + 1), ta[I & 1], tb[I & 1]);
 #undef W4B_SN
                 if constexpr (unit) uput(U{}, k1);
             });
             if constexpr (has_next) {
-                w4b_step_pv_fold<14, 1>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1]);
-                w4b_step_pv_fold<15, 0>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1]);
+                if constexpr (XB) {
+                    using N14 = std::integral_constant<int, 16 + 14 + D>;
+                    using N15 = std::integral_constant<int, 16 + 15 + D>;
+                    w4b_step_pv_fold<14, D, true, rd_off(N14{})>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1],
+                                                                 rd_addr(N14{}));
+                    w4b_step_pv_fold<15, D, true, rd_off(N15{})>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1],
+                                                                 rd_addr(N15{}));
+                } else {
+                    w4b_step_pv_fold<14, 1>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1]);
+                    w4b_step_pv_fold<15, 0>(pb[0][3], pb[1][3], cx[0][0], cy[0][0], cx[0][1], cy[0][1], cx[1][0], cy[1][0], cx[1][1], cy[1][1], tx[0], tx[1]);
+                }
                 mx_cur[0] = cx[0][0];
                 mx_cur[1] = cx[1][0];
             } else {
@@ -427,7 +497,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
                 w4b_step_pv<15, 0, false, 0, false, 0>(0u, pb[0][3], pb[1][3], 0.f, 0.f, kd, d0, d1, d0, d1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, d0, d1);
             }
         }
-        if (has_next && !(G3_AB_ATTN_ABLATE & 64)) lds_dma_publish_barrier();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
+        if (!XB && has_next && !(G3_AB_ATTN_ABLATE & 64)) lds_dma_publish_barrier();  // drains the LDS-DMA (vmcnt(0)) and publishes K(t+2) / V(t+1)
     };
 
     using True = std::integral_constant<bool, true>;
@@ -449,7 +519,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
     w4b_fence_acc();
     static_for<0, 2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
-        const float inv = 1.0f / xor32_sum((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3]));
+        const float extra = (XB && h == 0) ? (pe[0][0] + pe[0][1]) + (pe[1][0] + pe[1][1]) : 0.f;
+        const float inv = 1.0f / xor32_sum(((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3])) + extra);
         const int q_idx = blockIdx.x * W4_BQ + wave * 64 + 32 * h + l31;
         bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
         static_for<0, 16>([&](auto cc) {  // (d, q4): 4 consecutive output dims per store

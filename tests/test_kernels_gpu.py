@@ -121,7 +121,7 @@ def _attn_ref(q, k, v, Sq, Skv, B, H):
     return (p @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all", "attn_w4", "attn_w4b"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], ids=["attn_v1", "attn_v2", "attn_v3", "attn_v3fold_long", "attn_v3fold_all", "attn_mw_default", "attn_mw_fold_all", "attn_mw_nofold_all", "attn_w4", "attn_w4b", "attn_w4b_xb"])
 def attn_variant(request):
     from gen3c_amd import ops
     ops.set_option("attn_variant", request.param)
@@ -235,7 +235,7 @@ def test_flash_attn_segmented_vt_matches_plain():
         assert torch.equal(out, ref), (Sq, S_loc, n, B, H)
 
 
-@pytest.mark.parametrize("variant", [9, 10], ids=["attn_w4", "attn_w4b"])
+@pytest.mark.parametrize("variant", [9, 10, 11], ids=["attn_w4", "attn_w4b", "attn_w4b_xb"])
 def test_flash_attn_one_wave_per_simd_long_context(variant):
     """The one-wave-per-SIMD kernels (attention_w4.hpp / attention_w4b.hpp) on what their hand-laid tile stream has to get right: many tiles
     (ring slots and LDS-DMA bases wrap), keys whose scores tower over the running maximum late in the context (rescale branch with fragment

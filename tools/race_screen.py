@@ -62,7 +62,7 @@ for (Sq, Skv, H, segs) in [(56320, 56320, 4, 1), (7040, 56320, 4, 8), (1000, 449
         sl = Skv // segs
         vt = torch.stack([ops.transpose_v(v[i * sl:(i + 1) * sl], sl, 1, H) for i in range(segs)]).contiguous()
     ld = vt.shape[-1]
-    for variant in (3, 4, 6, 8, 9, 10):
+    for variant in (3, 4, 6, 8, 9, 10, 11):
         def run(lib):
             lib.g3_set_option(b"attn_variant", variant)
             o = torch.empty_like(q)
