@@ -40,12 +40,13 @@ def dit_forward_flops(N, D=4096, M=512, Dctx=1024, L=28, patch_dim=328, out_dim=
 
 
 def cpu_baseline(threads: int):
-    """Oracle ('port') timed on the host cores on a bounded sample: ONE Cosmos-7B-width block (D=4096, 32 heads,
-    MLP 16384, context 512x1024) on a 4 096-token latent [16,4,64,64], fp32, 4 repetitions, extrapolated by FLOPs to the
-    full step (the full-size CPU step would take ~3 h)."""
+    """Oracle ('port') timed on the host cores on a bounded sample of BASELINE.json's configs[0] shape: ONE Cosmos-7B-width block
+    (D=4096, 32 heads, MLP 16384, context 512x1024) of a DiT forward on the 16x64x64 latent = 16 384 tokens, fp32, once. Measured: that
+    block (incl. patch embedding / final layer). Extrapolated by FLOPs: the other 27 blocks, the second forward of the step and the
+    56 320-token size of configs[1] (the full-size CPU step would take ~1.7 h)."""
     from oracle import dit_oracle
     torch.set_num_threads(threads)
-    D, H, T, Hh, Ww, M = 4096, 32, 4, 64, 64, 512
+    D, H, T, Hh, Ww, M = 4096, 32, 16, 64, 64, 512
     g = torch.Generator().manual_seed(0)
     sd = {}
     def W(*s, scale=0.02):
@@ -73,7 +74,7 @@ def cpu_baseline(threads: int):
     mask = torch.zeros(1, 1, T, Hh, Ww)
     ctx = torch.randn(1, M, 1024, generator=g) * 0.2
     N = T * (Hh // 2) * (Ww // 2)
-    reps = 4
+    reps = 1
     t0 = time.perf_counter()
     with torch.no_grad():
         for _ in range(reps):
@@ -84,8 +85,8 @@ def cpu_baseline(threads: int):
     rate = flops / dt
     step_flops = 2 * dit_forward_flops(56320)
     return dict(value=rate / step_flops, unit="denoise-steps/sec", cores=threads, kind="port",
-                sample=f"oracle/dit_oracle.py fp32, 1 of 28 blocks (D=4096,H=32) on {N} tokens x{reps}: {dt:.1f}s = {rate/1e12:.3f} TFLOP/s, "
-                       f"extrapolated by FLOPs to the 4.419 PFLOP step")
+                sample=f"oracle/dit_oracle.py fp32: 1 of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, measured "
+                       f"{dt:.1f}s = {rate/1e12:.3f} TFLOP/s; extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step)")
 
 
 def self_launch_argv(n_gpus: int, argv: list, port: int | None = None) -> list:

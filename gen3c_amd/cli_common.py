@@ -102,7 +102,7 @@ def write_video(video: np.ndarray, fps: int, path_base: str, quality: int = 5, l
     except ImportError:
         pass
     log(f"[gen3c_amd] no mp4 encoder importable (imageio / cv2): writing {path_base}.npz (uint8 video [T,H,W,3] + fps)")
-    np.savez_compressed(path_base + ".npz", video=video, fps=fps)
+    np.savez(path_base + ".npz", video=video, fps=fps)  # uncompressed: zlib over a 121x704x1280 video costs 18 s, as much as five denoise steps
     return path_base + ".npz"
 
 

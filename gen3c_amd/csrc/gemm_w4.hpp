@@ -9,12 +9,13 @@
 //   * a K tile (64) = 4 k-step statements of 16 MFMAs; the fragments of k-step s + 1 are read while k-step s multiplies (s = 3: the first
 //     k-step of the NEXT tile, from the other LDS stage), so no LDS latency is exposed;
 //   * 2 LDS stages of 64 KiB ([256 feature rows][64 k] + [256 token rows][64 k], chunk index XOR-swizzled as in the other kernels). ONE barrier
-//     per K tile, after k-step 2, behind `s_waitcnt vmcnt(0) lgkmcnt(0)`: it publishes tile t + 1 (LDS-DMA issued during k-step 3 of tile t - 1
-//     and k-step 0 of tile t) and certifies that every wave holds the k-step-3 fragments of tile t in registers, which frees tile t's stage:
-//     its refill with tile t + 2 starts in k-step 3 (weight rows) and completes in k-step 0 of tile t + 1 (token rows) - every LDS-DMA piece
-//     has >= 2 k-steps (>= 1 000 cycles) to land;
-//   * an LDS-DMA piece is `s_add m0` + `global_load_lds_dwordx4` behind an MFMA; its 16 per-lane source offsets are loop-invariant VGPRs
-//     (rows clamped to the matrix, so M / N tails read valid memory and are never stored), the K position is the wave-uniform base.
+//     per K tile, after k-step 2, behind `s_waitcnt vmcnt(0) lgkmcnt(0)`: it publishes tile t + 1 (LDS-DMA issued from k-step 3 of tile t - 1
+//     through k-step 1 of tile t) and certifies that every wave holds the k-step-3 fragments of tile t in registers, which frees tile t's stage:
+//     its refill with tile t + 2 starts in k-step 3 and continues through k-steps 0 and 1 of tile t + 1 (6 + 5 + 5 pieces, one per ~3 MFMAs:
+//     a rate the vector memory path absorbs; k-step 2, the one in front of the barrier, issues none);
+//   * an LDS-DMA piece is `s_mov m0` one MFMA gap ahead + `global_load_lds_dwordx4` behind an MFMA; its 16 per-lane source offsets are
+//     loop-invariant VGPRs (rows clamped to the matrix, so M / N tails read valid memory and are never stored), the K position is the
+//     wave-uniform base.
 // Needs K % 64 == 0, K >= 128 and the full-line epilogue's alignment (host: launch()); everything else runs on the ping-pong kernel.
 
 #define GW4_ACC_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
@@ -46,17 +47,28 @@ template <int R> G3_DEVICE float gw4_acc_read() {
 #endif
 // MFMA (i, j) on buffer B:  a[16 (4 j + i)] += W_i . T_j^T
 #define GW4_MM(I, J) "v_mfma_f32_32x32x16_bf16 a[%c[d" #I #J "]:%c[z" #I #J "]], v[%c[w" #I "]:%c[x" #I "]], v[%c[t" #J "]:%c[u" #J "]], a[%c[d" #I #J "]:%c[z" #I #J "]]\n\t"
+// LDS-DMA piece Q of a statement: its LDS destination goes into M0 one gap earlier (GW4_M0), the load itself sits behind the next MFMA (GW4_LD)
 #if G3_AB_GW4_ABLATE & 4
-#define GW4_DMA(Q) ""
+#define GW4_M0(Q) ""
+#define GW4_LD(Q) ""
 #else
-#define GW4_DMA(Q) "global_load_lds_dwordx4 %[vo" #Q "], %[sb]\n\ts_add_u32 m0, m0, 0x400\n\t"
+#define GW4_M0(Q) "s_mov_b32 m0, %[m" #Q "]\n\t"
+#define GW4_LD(Q) "global_load_lds_dwordx4 %[vo" #Q "], %[sb" #Q "]\n\t"
 #endif
 
+struct GW4Pieces {  // up to 6 pieces per k-step statement: LDS destination, per-lane source byte offset, wave-uniform source base
+    uint32_t m[6];
+    uint32_t vo[6];
+    const char* sb[6];
+};
+
 // One k-step: wait for this k-step's fragments (buffer KS & 1), 16 MFMAs; between them the 8 fragment reads of the next k-step (other buffer)
-// when READ, and 8 LDS-DMA pieces when DMA (destinations m0v + 1 KiB q, per-lane source offsets vo[q] from the wave-uniform base sb).
+// when READ, and NP (0, 5 or 6) LDS-DMA pieces spread evenly over the MFMA gaps: four waves issuing one 1 KiB piece per ~3 MFMAs ask the
+// vector memory path for ~43 B/clk/CU (its peak is 64) - issued back to back (8 per k-step, round 2's first form) they queue up and the
+// issue stall lands on the only wave that can feed the matrix pipe.
 // BAR: behind the MFMAs wait for all LDS reads and LDS-DMA of this wave and join the workgroup barrier.
-template <int KS, bool READ, bool DMA, bool BAR>
-G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, uint32_t m0v, const char* sb, const uint32_t (&vo)[8]) {
+template <int KS, bool READ, int NP, bool BAR>
+G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
     constexpr int cur = GW4_FRAG0 + 32 * (KS & 1), nxt = GW4_FRAG0 + 32 * ((KS & 1) ^ 1);
 #define GW4_OPS_MM(I, J) [d##I##J] "n"(16 * (4 * J + I)), [z##I##J] "n"(16 * (4 * J + I) + 15)
 #define GW4_OPS_ALLMM GW4_OPS_MM(0, 0), GW4_OPS_MM(1, 0), GW4_OPS_MM(2, 0), GW4_OPS_MM(3, 0), GW4_OPS_MM(0, 1), GW4_OPS_MM(1, 1), GW4_OPS_MM(2, 1), GW4_OPS_MM(3, 1), \
@@ -69,7 +81,7 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, uint32_t m0v, const char* s
                    [ad0] "v"(adw), [ad1] "v"(adw), [ad2] "v"(adw), [ad3] "v"(adw), [ad4] "v"(adt), [ad5] "v"(adt), [ad6] "v"(adt), [ad7] "v"(adt), \
                    [o0] "n"(0), [o1] "n"(4096), [o2] "n"(8192), [o3] "n"(12288), [o4] "n"(GW4_T_OFF), [o5] "n"(GW4_T_OFF + 4096), [o6] "n"(GW4_T_OFF + 8192), \
                    [o7] "n"(GW4_T_OFF + 12288)
-#define GW4_OPS_DMA [m0v] "s"(m0v), [sb] "s"(sb), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]), [vo6] "v"(vo[6]), [vo7] "v"(vo[7])
+#define GW4_OPS_P(Q) [m##Q] "s"(pc.m[Q]), [vo##Q] "v"(pc.vo[Q]), [sb##Q] "s"(pc.sb[Q])
 #if G3_AB_GW4_ABLATE & 2
 #define GW4_BARRIER "s_waitcnt lgkmcnt(0)\n\t"
 #elif G3_AB_GW4_ABLATE & 1
@@ -78,27 +90,34 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, uint32_t m0v, const char* s
 #define GW4_BARRIER "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"
 #endif
     // token fragments of the previous k-step were last read by its MFMAs (j-major order: T_0 first), so they are overwritten first
-    if constexpr (READ && DMA && !BAR)
-        asm volatile("s_mov_b32 m0, %[m0v]\n\ts_waitcnt lgkmcnt(0)\n\t"
-                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
-                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
-                     GW4_MM(0, 2) GW4_DMA(0) GW4_MM(1, 2) GW4_DMA(1) GW4_MM(2, 2) GW4_DMA(2) GW4_MM(3, 2) GW4_DMA(3)
-                     GW4_MM(0, 3) GW4_DMA(4) GW4_MM(1, 3) GW4_DMA(5) GW4_MM(2, 3) GW4_DMA(6) GW4_MM(3, 3) GW4_DMA(7)
-                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_DMA : GW4_OWNED, "memory");
-    else if constexpr (READ && !DMA && !BAR)
+    if constexpr (READ && NP == 6 && !BAR)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_M0(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_LD(0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7) GW4_M0(1)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_LD(1) GW4_MM(1, 1) GW4_RD(N, 1) GW4_M0(2) GW4_MM(2, 1) GW4_RD(N, 2) GW4_LD(2) GW4_MM(3, 1) GW4_RD(N, 3)
+                     GW4_MM(0, 2) GW4_M0(3) GW4_MM(1, 2) GW4_LD(3) GW4_MM(2, 2) GW4_MM(3, 2) GW4_M0(4)
+                     GW4_MM(0, 3) GW4_LD(4) GW4_MM(1, 3) GW4_M0(5) GW4_MM(2, 3) GW4_LD(5) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_P(0), GW4_OPS_P(1), GW4_OPS_P(2), GW4_OPS_P(3), GW4_OPS_P(4), GW4_OPS_P(5) : GW4_OWNED, "memory");
+    else if constexpr (READ && NP == 5 && !BAR)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_M0(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_LD(0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7) GW4_M0(1)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_LD(1) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_M0(2) GW4_MM(3, 1) GW4_RD(N, 3) GW4_LD(2)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_M0(3) GW4_MM(2, 2) GW4_LD(3) GW4_MM(3, 2)
+                     GW4_MM(0, 3) GW4_M0(4) GW4_MM(1, 3) GW4_LD(4) GW4_MM(2, 3) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_P(0), GW4_OPS_P(1), GW4_OPS_P(2), GW4_OPS_P(3), GW4_OPS_P(4) : GW4_OWNED, "memory");
+    else if constexpr (READ && NP == 0 && !BAR)
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
                      GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
                      GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3)
                      : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD : GW4_OWNED, "memory");
-    else if constexpr (READ && !DMA && BAR)
+    else if constexpr (READ && NP == 0 && BAR)
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
                      GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
                      GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3) GW4_BARRIER
                      : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD : GW4_OWNED, "memory");
     else {
-        static_assert(!READ && !DMA && !BAR, "gw4_kstep: combination not laid out");
+        static_assert(!READ && NP == 0 && !BAR, "gw4_kstep: combination not laid out");
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      GW4_MM(0, 0) GW4_MM(1, 0) GW4_MM(2, 0) GW4_MM(3, 0) GW4_MM(0, 1) GW4_MM(1, 1) GW4_MM(2, 1) GW4_MM(3, 1)
                      GW4_MM(0, 2) GW4_MM(1, 2) GW4_MM(2, 2) GW4_MM(3, 2) GW4_MM(0, 3) GW4_MM(1, 3) GW4_MM(2, 3) GW4_MM(3, 3)
@@ -188,8 +207,11 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
         };
         dma8(w_tile, vo_w, m0_w);
         dma8(t_tile, vo_t, m0_t);
-        dma8(w_tile + 128, vo_w, m0_w + GW4_STAGE_BYTES);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 6; ++q)  // weight pieces 0..5 of tile 1 (what k-step 3 of "tile -1" would have issued)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + 128 + vo_w[q]),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
         asm volatile("ds_read_b128 v[192:195], %0\n\tds_read_b128 v[196:199], %0 offset:4096\n\tds_read_b128 v[200:203], %0 offset:8192\n\t"
                      "ds_read_b128 v[204:207], %0 offset:12288\n\tds_read_b128 v[208:211], %1 offset:32768\n\tds_read_b128 v[212:215], %1 offset:36864\n\t"
@@ -197,21 +219,39 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
                      ::"v"(adw[0][0]), "v"(adt[0][0]) : GW4_OWNED, "memory");
     }
 
-    // K tile t in stage S = t & 1. DMA_A: token rows of tile t + 1 -> other stage (k-step 0); DMA_W: weight rows of tile t + 2 -> this stage
-    // (k-step 3, behind the barrier); NEXT: prefetch the first fragments of tile t + 1 in k-step 3.
-    auto ktile = [&](auto sc, auto dma_a_c, auto dma_w_c, auto next_c, int t) {
+    // K tile t in stage S = t & 1. The 16 LDS-DMA pieces of a tile (8 weight, 8 token row blocks of this wave) are issued over three k-steps:
+    // weight pieces 0..5 of tile t + 2 -> this stage in k-step 3 (behind the barrier that frees it), weight pieces 6, 7 + token pieces 0..2
+    // of tile t + 1 -> the other stage in k-step 0, token pieces 3..7 in k-step 1; k-step 2 issues none, so every piece has >= 1 k-step
+    // (the weight pieces >= 3) before the barrier's vmcnt(0). DMA_N: tile t + 1 exists; DMA_W: tile t + 2 exists; NEXT = DMA_N.
+    auto ktile = [&](auto sc, auto dma_n_c, auto dma_w_c, auto next_c, int t) {
         constexpr int S = decltype(sc)::value;
-        constexpr bool DMA_A = decltype(dma_a_c)::value, DMA_W = decltype(dma_w_c)::value, NEXT = decltype(next_c)::value;
+        constexpr bool DMA_N = decltype(dma_n_c)::value, DMA_W = decltype(dma_w_c)::value, NEXT = decltype(next_c)::value;
         constexpr int SO = S * GW4_STAGE_BYTES, SN = (S ^ 1) * GW4_STAGE_BYTES;
         G3_JITTER(wave + blockIdx.x, t);
-        gw4_kstep<0, true, DMA_A, false>(adw[S][1], adt[S][1], m0_t + SN, t_tile + (int64_t)(t + 1) * 128, vo_t);
-        gw4_kstep<1, true, false, false>(adw[S][2], adt[S][2], 0u, nullptr, vo_t);
+        const char* wn1 = w_tile + (int64_t)(t + 1) * 128;
+        const char* tn1 = t_tile + (int64_t)(t + 1) * 128;
+        const char* wn2 = w_tile + (int64_t)(t + 2) * 128;
+        GW4Pieces p0{}, p1{}, p3{};
+        if constexpr (DMA_N) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) p0.m[q] = m0_w + SN + 1024u * (6 + q), p0.vo[q] = vo_w[6 + q], p0.sb[q] = wn1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) p0.m[2 + q] = m0_t + SN + 1024u * q, p0.vo[2 + q] = vo_t[q], p0.sb[2 + q] = tn1;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) p1.m[q] = m0_t + SN + 1024u * (3 + q), p1.vo[q] = vo_t[3 + q], p1.sb[q] = tn1;
+        }
+        if constexpr (DMA_W) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) p3.m[q] = m0_w + SO + 1024u * q, p3.vo[q] = vo_w[q], p3.sb[q] = wn2;
+        }
+        gw4_kstep<0, true, DMA_N ? 5 : 0, false>(adw[S][1], adt[S][1], p0);
+        gw4_kstep<1, true, DMA_N ? 5 : 0, false>(adw[S][2], adt[S][2], p1);
         if constexpr (NEXT) {
-            gw4_kstep<2, true, false, true>(adw[S][3], adt[S][3], 0u, nullptr, vo_t);
-            gw4_kstep<3, true, DMA_W, false>(adw[S ^ 1][0], adt[S ^ 1][0], m0_w + SO, w_tile + (int64_t)(t + 2) * 128, vo_w);
+            gw4_kstep<2, true, 0, true>(adw[S][3], adt[S][3], p3);
+            gw4_kstep<3, true, DMA_W ? 6 : 0, false>(adw[S ^ 1][0], adt[S ^ 1][0], p3);
         } else {
-            gw4_kstep<2, true, false, false>(adw[S][3], adt[S][3], 0u, nullptr, vo_t);
-            gw4_kstep<3, false, false, false>(0u, 0u, 0u, nullptr, vo_t);
+            gw4_kstep<2, true, 0, false>(adw[S][3], adt[S][3], p3);
+            gw4_kstep<3, false, 0, false>(0u, 0u, p3);
         }
     };
     // residual rows of the epilogue (EPI_GATED_RESIDUAL / EPI_BIAS_RESIDUAL), in the epilogue's read-back layout: block J (32 tokens), pass s8:

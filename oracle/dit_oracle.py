@@ -85,9 +85,14 @@ def attention_sbhd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.T
     """DotProductAttention(no mask, scale 1/sqrt(d)) on [s,b,h,d] -> [s,b,h*d], fp32 softmax (attention.py:228-238,288)."""
     d = q.shape[-1]
     qf, kf, vf = (t.permute(1, 2, 0, 3).float() for t in (q, k, v))  # b h s d
-    scores = torch.matmul(qf, kf.transpose(-1, -2)) / math.sqrt(d)
-    p = torch.softmax(scores, dim=-1)
-    o = torch.matmul(p.to(v.dtype).float(), vf)
+    # heads are independent: long sequences go through in head groups so the score matrix stays below ~8 GB (same arithmetic per head)
+    hg = max(1, min(qf.shape[1], int(2e9 // max(1, qf.shape[0] * qf.shape[2] * kf.shape[2]))))
+    outs = []
+    for h0 in range(0, qf.shape[1], hg):
+        scores = torch.matmul(qf[:, h0:h0 + hg], kf[:, h0:h0 + hg].transpose(-1, -2)) / math.sqrt(d)
+        p = torch.softmax(scores, dim=-1)
+        outs.append(torch.matmul(p.to(v.dtype).float(), vf[:, h0:h0 + hg]))
+    o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     return o.permute(2, 0, 1, 3).reshape(q.shape[0], q.shape[1], -1).to(q.dtype)
 
 
