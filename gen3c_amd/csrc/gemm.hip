@@ -18,6 +18,7 @@
 //   * blockIdx is remapped so that the 8 XCDs each own a contiguous band of token tiles (private L2 reuse of
 //     the weight panel).
 #include "common.hpp"
+#include "gen3c_hip.h"
 #include <stdlib.h>
 #include <mutex>
 #include <type_traits>
@@ -29,7 +30,8 @@ constexpr int BN = 256;  // features per block tile
 constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3, EPI_BIAS_RESIDUAL = 4 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATED_RESIDUAL = 2, EPI_BIAS = 3, EPI_BIAS_RESIDUAL = 4,
+       EPI_QK_NORM_ROPE = 5 };  // 5: per-head RMSNorm (+ RoPE) on the q / k feature ranges (gemm_w4.hpp only; g3_gemm_qk_norm_rope_bf16)
 
 // Implicit-GEMM convolution geometry (channels-last activations [T][H][W][C], one batch item):
 // output row m = (to, yo, xo); tap (dt, dy, dx) reads input position
@@ -55,6 +57,8 @@ struct GemmParams {
     const bf16_t* R; int64_t ldr;                     // residual rows
     int tiles_m, tiles_n;
     ConvGeom cv;
+    // EPI_QK_NORM_ROPE: features [0, n_q) are q heads (weight nw_q), [n_q, n_q + n_k) k heads (nw_k), the rest is stored as is
+    const bf16_t* nw_q; const bf16_t* nw_k; const float* rope_cos; const float* rope_sin; int n_q, n_k, rope_B; float rms_eps;
 };
 
 G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
@@ -797,6 +801,44 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
             return launch<EPI_BIAS_RESIDUAL, false>(p, s, what);
         default: return g3_set_error(G3_ERR_ARG, "g3_gemm_bf16_nt: unknown epilogue %d", epilogue);
     }
+}
+
+// Q / K projection with the per-head RMSNorm (+ RoPE) of the reference's Attention.cal_qkv (attention.py:247-280) in the epilogue:
+//   C[:, 0:n_q]         = rope(rmsnorm(A W^T, norm_q))     C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k))     C[:, n_q+n_k:] = A W^T
+// Row m is token (s = m / B, b = m % B); cos / sin are fp32 [S][128] (NULL: no RoPE - cross-attention). Same rounding points as
+// g3_gemm_bf16_nt followed by g3_qk_rmsnorm_rope_bf16 in place, which is also what runs when the one-wave-per-SIMD kernel does not apply.
+extern "C" int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                                         int n_q, int n_k, const void* norm_q, const void* norm_k, const float* cos_table,
+                                         const float* sin_table, int B, float eps, void* stream) {
+    if (!A || !W || !C) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: null operand");
+    if (M <= 0 || N <= 0 || K <= 0 || B <= 0 || (M % B)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: bad shape M=%d N=%d K=%d B=%d", M, N, K, B);
+    if (n_q < 0 || n_k < 0 || (n_q % 128) || (n_k % 128) || n_q + n_k > N || (N % 128))
+        return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: q / k feature ranges must be whole 128-wide heads inside N (n_q=%d n_k=%d N=%d)", n_q, n_k, N);
+    if ((n_q && !norm_q) || (n_k && !norm_k)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: missing norm weight");
+    if ((cos_table == nullptr) != (sin_table == nullptr)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: need both cos and sin tables or neither");
+    if ((K & 7) || (lda & 7) || (ldw & 7) || (ldc & 7)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: K, lda, ldw, ldc must be multiples of 8");
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) || (((uintptr_t)norm_q | (uintptr_t)norm_k) & 15) || (((uintptr_t)cos_table | (uintptr_t)sin_table) & 15))
+        return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: operands must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = (K % BK) == 0 && K >= 2 * BK && !g3_opt_gemm_regstage && g3_opt_gemm_pingpong == 3 && g3_opt_gemm_wide_store;
+    if (fused) {
+        GemmParams p;
+        p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = (bf16_t*)C; p.ldc = ldc;
+        p.M = M; p.N = N; p.K = K;
+        p.gate = nullptr; p.gate_rows = 1; p.ldg = 0; p.R = nullptr; p.ldr = 0;
+        p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+        p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
+        p.wide_store = 1;
+        p.cv = ConvGeom{};
+        p.nw_q = (const bf16_t*)norm_q; p.nw_k = (const bf16_t*)norm_k; p.rope_cos = cos_table; p.rope_sin = sin_table;
+        p.n_q = n_q; p.n_k = n_k; p.rope_B = B; p.rms_eps = eps;
+        return launch_w4<EPI_QK_NORM_ROPE>(p, s, "g3_gemm_qk_norm_rope_bf16");
+    }
+    int rc = g3_gemm_bf16_nt(A, lda, W, ldw, C, ldc, M, N, K, EPI_NONE, nullptr, 1, 0, nullptr, 0, stream);
+    bf16_t* c = (bf16_t*)C;
+    if (rc == G3_OK && n_q) rc = g3_qk_rmsnorm_rope_bf16(c, ldc, norm_q, cos_table, sin_table, c, ldc, M / B, B, n_q / 128, 128, eps, stream);
+    if (rc == G3_OK && n_k) rc = g3_qk_rmsnorm_rope_bf16(c + n_q, ldc, norm_k, cos_table, sin_table, c + n_q, ldc, M / B, B, n_k / 128, 128, eps, stream);
+    return rc;
 }
 
 // Causal 3-D convolution as an implicit GEMM over channels-last activations.

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
         bid = base + slot;
     }
     int tile_m, tile_n;
-    if (p.tile_order_rowmajor) {
+    if (p.tile_order_rowmajor == 1) {
         tile_m = bid / p.tiles_n;
         tile_n = bid - tile_m * p.tiles_n;
     } else {
-        constexpr int GM = 4;
+        const int GM = p.tile_order_rowmajor >= 2 ? p.tile_order_rowmajor : 4;  // option values >= 2: super-row height for A/B runs
         const int per_group = GM * p.tiles_n;
         const int grp = bid / per_group;
         const int within = bid - grp * per_group;
@@ -301,9 +301,30 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
         char* stage = smem_raw + wave * 16384;
         const int n = n0 + wn * 128 + 8 * c2;
         bf16x8 gv1 = zero_bf16x8();
-        if (EPI != EPI_NONE && EPI != EPI_GELU && p.gate_rows == 1 && n < p.N) gv1 = load_bf16x8(p.gate + n);
+        if (EPI != EPI_NONE && EPI != EPI_GELU && EPI != EPI_QK_NORM_ROPE && p.gate_rows == 1 && n < p.N) gv1 = load_bf16x8(p.gate + n);
+        int qk_type = 0;
+        bf16x8 nwv = zero_bf16x8();
+        if (EPI == EPI_QK_NORM_ROPE) {
+            const int nh = n0 + wn * 128;  // first feature of this wave's head
+            qk_type = nh < p.n_q ? 1 : (nh < p.n_q + p.n_k ? 2 : 0);
+            if (qk_type != 0) nwv = load_bf16x8((qk_type == 1 ? p.nw_q : p.nw_k) + 8 * c2);
+        }
         static_for<0, 4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
+            // EPI_QK_NORM_ROPE: the cos / sin entries of this lane's 8 features for the 8 token rows of the block, requested before the
+            // accumulators are moved (64 v_accvgpr_read + the LDS transpose cover most of their latency)
+            f32x4 tcos[EPI == EPI_QK_NORM_ROPE ? 8 : 1][2], tsin[EPI == EPI_QK_NORM_ROPE ? 8 : 1][2];
+            if (EPI == EPI_QK_NORM_ROPE && qk_type != 0 && p.rope_cos != nullptr) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const int m = min(m0 + wm * 128 + 32 * J + 4 * s8 + rsub, p.M - 1);
+                    const int64_t o = (int64_t)(m / p.rope_B) * 128 + 8 * c2;
+                    tcos[s8][0] = *reinterpret_cast<const f32x4*>(p.rope_cos + o);
+                    tcos[s8][1] = *reinterpret_cast<const f32x4*>(p.rope_cos + o + 4);
+                    tsin[s8][0] = *reinterpret_cast<const f32x4*>(p.rope_sin + o);
+                    tsin[s8][1] = *reinterpret_cast<const f32x4*>(p.rope_sin + o + 4);
+                }
+            }
             f32x16 acc[4];
             static_for<0, 64>([&](auto rc) {
                 constexpr int R = decltype(rc)::value;
@@ -331,7 +352,46 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
                     v[e] = lo[e];
                     v[4 + e] = hi[e];
                 }
-                if (EPI == EPI_GELU) {
+                if (EPI == EPI_QK_NORM_ROPE) {
+                    // nn.Linear rounds to bf16; per-head RMSNorm in fp32 -> bf16 (te RMSNorm); RoPE in fp32 -> bf16: the rounding points of
+                    // qk_rmsnorm_rope_kernel (norm_rope.hip). A head's 128 features of this row sit in the 16 lanes c2 = 0..15 of this lane's
+                    // row group; feature d pairs with d +- 64 = lane c2 ^ 8 (rotate_half).
+                    if (qk_type != 0) {  // wave-uniform: 0 = plain features (v), 1 = q head, 2 = k head
+                        float ss = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v[e] = (float)f32_to_bf16(v[e]);
+                            ss += v[e] * v[e];
+                        }
+                        ss += __shfl_xor(ss, 1, 64);
+                        ss += __shfl_xor(ss, 2, 64);
+                        ss += __shfl_xor(ss, 4, 64);
+                        ss += __shfl_xor(ss, 8, 64);
+                        const float rinv = rsqrtf(ss * (1.0f / 128.0f) + p.rms_eps);
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)f32_to_bf16(v[e] * rinv * (float)nwv[e]);
+                        if (p.rope_cos != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                bf16x2 t2;
+                                t2[0] = f32_to_bf16(v[2 * e]);
+                                t2[1] = f32_to_bf16(v[2 * e + 1]);
+                                pk[e] = __shfl_xor(__builtin_bit_cast(uint32_t, t2), 8, 64);
+                            }
+                            const float sgn = (c2 & 8) ? 1.f : -1.f;  // first half: t cos - t2 sin; second half: t2 cos + t sin
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const bf16x2 t2 = __builtin_bit_cast(bf16x2, pk[e >> 1]);
+                                const float other = (float)t2[e & 1];
+                                const float cs = e < 4 ? tcos[s8][0][e & 3] : tcos[s8][1][e & 3];
+                                const float sn = e < 4 ? tsin[s8][0][e & 3] : tsin[s8][1][e & 3];
+                                const float a = v[e] * cs, b = other * sn;
+                                v[e] = sgn < 0.f ? a - b : a + b;
+                            }
+                        }
+                    }
+                } else if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
                 } else if (EPI != EPI_NONE) {

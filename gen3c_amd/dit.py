@@ -416,24 +416,21 @@ class VideoExtendGeneralDIT(nn.Module):
             if self._cp_attn is not None:
                 # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
                 # every output element sees the same K order, so this is bit-identical to the single fused GEMM)
-                kv = ops.gemm_nt(h, blk["fa_qkv"][D:])  # [S*B, 2D]
-                k = ops.qk_rmsnorm_rope(kv[:, :D], blk["fa_kn"], cos, sin, S, B, nH)
-                pending = self._cp_attn.start(k, kv[:, D:], S, B, nH)
-                q = ops.qk_rmsnorm_rope(ops.gemm_nt(h, blk["fa_qkv"][:D]), blk["fa_qn"], cos, sin, S, B, nH)
+                # the per-head RMSNorm + RoPE of q and k (attention.py:262-280) run in the projections' epilogues
+                kv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"][D:], 0, D, None, blk["fa_kn"], cos, sin, S, B)  # [S*B, 2D]: k normalised + rotated, v plain
+                pending = self._cp_attn.start(kv[:, :D], kv[:, D:], S, B, nH)
+                q = ops.gemm_qk_norm_rope(h, blk["fa_qkv"][:D], D, 0, blk["fa_qn"], None, cos, sin, S, B)
                 o = self._cp_attn.finish(q, pending)
             else:
-                qkv = ops.gemm_nt(h, blk["fa_qkv"])  # [S*B, 3D]
-                q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH)
-                k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH)
-                v = qkv[:, 2 * D:]
+                qkv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B)  # [S*B, 3D]
+                q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
                 vt = ops.transpose_v(v, S, B, nH)
                 o = ops.flash_attn(q, k, vt, S, S, B, nH)
             ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- cross attention (unmasked over all M context tokens, general_dit.py:407-410)
             shift, scale, gate = self._modulation(emb, blk["ada"][1], adaln_lora, 3)
             h = ops.layernorm_modulate(xs, shift, scale)
-            q = ops.gemm_nt(h, blk["ca_q"])
-            q = ops.qk_rmsnorm_rope(q, blk["ca_qn"], None, None, S, B, nH)
+            q = ops.gemm_qk_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B)
             k, vt = ca_kv[bi]
             o = ops.flash_attn(q, k, vt, S, M, B, nH)
             ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)

@@ -156,6 +156,36 @@ def qk_rmsnorm_rope(x: torch.Tensor, weight: torch.Tensor, cos: Optional[torch.T
     return out
 
 
+def gemm_qk_norm_rope(a: torch.Tensor, w: torch.Tensor, n_q: int, n_k: int, norm_q: Optional[torch.Tensor], norm_k: Optional[torch.Tensor],
+                      cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None,
+                      eps: float = 1e-6) -> torch.Tensor:
+    """out[M,N] = a @ w^T with per-head RMSNorm (+ RoPE) applied to the feature ranges [0, n_q) (weight norm_q) and [n_q, n_q+n_k) (norm_k)
+    in the GEMM epilogue; the remaining features (v) are stored as they are. Replaces gemm_nt + qk_rmsnorm_rope on views of its output."""
+    M, K, lda = _rowmajor2d(a, "a")
+    N, Kw, ldw = _rowmajor2d(w, "w")
+    assert K == Kw and M == S * B
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    Mo, No, ldc = _rowmajor2d(out, "out")
+    assert (Mo, No) == (M, N)
+    cp = sp = 0
+    if cos is not None:
+        assert cos.shape == (S, 128) and sin.shape == (S, 128) and cos.is_contiguous() and sin.is_contiguous()
+        cp, sp = _dev(cos, "cos", torch.float32), _dev(sin, "sin", torch.float32)
+    lib = _lib.load()
+    timer = None
+    if _KERNEL_TIMERS is not None and M >= 4096:
+        timer = HipTimer()
+        timer.start()
+    _lib.check(lib.g3_gemm_qk_norm_rope_bf16(_dev(a, "a"), lda, _dev(w, "w"), ldw, _dev(out, "out"), ldc, M, N, K, n_q, n_k,
+                                             _dev(norm_q, "norm_q") if n_q else 0, _dev(norm_k, "norm_k") if n_k else 0, cp, sp, B, eps, _stream()),
+               "g3_gemm_qk_norm_rope_bf16")
+    if timer is not None:
+        timer.stop()
+        _KERNEL_TIMERS.append(("gemm_nt", dict(M=M, N=N, K=K, epilogue=5), timer))
+    return out
+
+
 def ceil_to(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 

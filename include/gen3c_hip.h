@@ -101,6 +101,14 @@ int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, c
                             const float* sin_table, void* out, int64_t ld_out, int S, int B, int H, int head_dim,
                             float eps, void* stream);
 
+/* Q / K(/V) projection with that per-head RMSNorm (+ RoPE) in the GEMM's epilogue (Attention.cal_qkv, attention.py:247-280, as one call):
+ *   C[:, 0:n_q] = rope(rmsnorm(A W^T, norm_q)),  C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k)),  C[:, n_q+n_k:N] = A W^T (e.g. v).
+ * Row m is token (s = m / B, b = m % B); n_q, n_k, N multiples of 128 (whole heads); cos / sin fp32 [M/B][128] or both NULL. Same
+ * rounding points as g3_gemm_bf16_nt followed by g3_qk_rmsnorm_rope_bf16 in place (which is what runs where the fused kernel does not apply). */
+int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                              int n_q, int n_k, const void* norm_q, const void* norm_k, const float* cos_table,
+                              const float* sin_table, int B, float eps, void* stream);
+
 /* Top of a DiT block in ONE pass over x:  x += extra_per_block_pos_emb  (in place; blocks.py:547-548), then
  * out = LayerNorm(x) * (1 + scale) + shift  as g3_layernorm_modulate_bf16. The [S*B, D] embedding is not read from memory: it is
  * rebuilt per row from LearnablePosEmbAxis' three tables pe_t [T,D], pe_h [Hp,D], pe_w [Wp,D] with the reference's bf16 rounding

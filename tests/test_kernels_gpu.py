@@ -97,6 +97,40 @@ def test_gemm_nt(M, N, K, epi, regstage):
     assert _rel_l2(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("S,B,H,K,mode", [(512, 1, 4, 512, "qkv"), (300, 2, 2, 256, "qkv"), (1000, 1, 2, 1024, "kv"), (640, 1, 3, 384, "q"), (256, 2, 2, 256, "q_norope"),
+                                          (7040, 1, 32, 4096, "qkv")])
+def test_gemm_qk_norm_rope_epilogue_matches_unfused(S, B, H, K, mode):
+    """g3_gemm_qk_norm_rope_bf16 (RMSNorm + RoPE in the projection's epilogue, gemm_w4.hpp) against the same projection followed by the
+    standalone qk_rmsnorm_rope kernel: identical rounding points; the only difference is the fp32 summation order of the 128 squares."""
+    from gen3c_amd import ops
+    dev = _dev()
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(S + K + H)
+    a = torch.randn(S * B, K, device=dev, generator=g).to(torch.bfloat16)
+    n_q, n_k, n_v = {"qkv": (D, D, D), "kv": (0, D, D), "q": (D, 0, 0), "q_norope": (D, 0, 0)}[mode]
+    N = n_q + n_k + n_v
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    wq = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    wk = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    cos = sin = None
+    if mode != "q_norope":
+        ang = torch.randn(S, 128, device=dev, generator=g) * 3
+        cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    fused = ops.gemm_qk_norm_rope(a, w, n_q, n_k, wq if n_q else None, wk if n_k else None, cos, sin, S, B)
+    ref = ops.gemm_nt(a, w)
+    if n_q:
+        ops.qk_rmsnorm_rope(ref[:, :n_q], wq, cos, sin, S, B, n_q // 128, out=ref[:, :n_q])
+    if n_k:
+        ops.qk_rmsnorm_rope(ref[:, n_q:n_q + n_k], wk, cos, sin, S, B, n_k // 128, out=ref[:, n_q:n_q + n_k])
+    torch.cuda.synchronize()
+    if n_v:
+        assert torch.equal(fused[:, n_q + n_k:], ref[:, n_q + n_k:]), "plain (v) features must be untouched"
+    same = float((fused == ref).float().mean())
+    diff = float((fused.float() - ref.float()).abs().max())
+    print(f"[gemm_qk_norm_rope {mode} S={S} B={B} H={H} K={K}] identical {same * 100:.3f} % of elements, max abs diff {diff:.3e}")
+    assert same > 0.995 and diff <= 2.0 ** -5 * float(ref.float().abs().max())  # at most one bf16 ulp, on a few elements
+
+
 def test_gemm_inplace_residual_and_gate_rows():
     from gen3c_amd import ops
     dev = _dev()
