@@ -89,6 +89,58 @@ def cpu_baseline(threads: int):
                        f"{dt:.1f}s = {rate/1e12:.3f} TFLOP/s; extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step)")
 
 
+def stage_rooflines(dev):
+    """The chunk's other two stages at the benchmark size, timed once each with hipEvents (rank 0, N = 1, outside the timed region):
+    tokenizer encode / decode of one 121x704x1280 clip (algorithmic work SURVEY.md 8a-a15: 35.7 / 61.3 TFLOP, MFMA-bound) and the cache
+    renderer (algorithmic 43.2 MB per 704x1280 item, SURVEY.md 8d, HBM-bound). Random weights / synthetic scene."""
+    from gen3c_amd import ops, renderer
+    from gen3c_amd.tokenizer import CausalVideoTokenizerNet
+    out = {}
+    net = CausalVideoTokenizerNet(channels=128, device=dev)
+    net.init_random(seed=0)
+    x = (torch.rand(1, 3, 121, 704, 1280, device=dev) * 2 - 1).to(torch.bfloat16)
+    z = None
+    tok = {}
+    for name, fn, tflop in (("encode", net.encoder, 35.7), ("decode", net.decoder, 61.3)):
+        arg = x if name == "encode" else z
+        res = fn(arg)  # warm-up (also the decode input)
+        torch.cuda.synchronize()
+        tm = ops.HipTimer()
+        tm.start()
+        res = fn(arg)
+        tm.stop()
+        ms = tm.elapsed_ms()
+        tok[name] = dict(ms=round(ms, 2), achieved=round(tflop / ms * 1e3, 1), frac=round(tflop / ms * 1e3 / PEAK_BF16_TFLOPS, 4))
+        if name == "encode":
+            z = res
+    out["roofline_tokenizer"] = dict(bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_TFLOPS, workload="CV8x8x8 tokenizer, one 121x704x1280 clip, bf16", **tok)
+    del net, x, z, res
+    h, w, F = 704, 1280, 32
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
+    depth = 4.0 + 0.0004 * xs + 0.0002 * ys
+    for (cy, cx, r, zz) in ((h * 0.4, w * 0.3, h * 0.22, 1.6), (h * 0.65, w * 0.7, h * 0.18, 2.4)):
+        depth = torch.where((ys - cy) ** 2 + (xs - cx) ** 2 < r * r, zz + 0.0001 * xs, depth)
+    img = torch.stack([torch.sin(xs * 0.021 + c) * torch.cos(ys * 0.017 - c) for c in range(3)], 0)
+    K = torch.tensor([[1000.0, 0, w / 2], [0, 1000.0, h / 2], [0, 0, 1]], device=dev)
+    w2cs = torch.eye(4, device=dev).repeat(1, F, 1, 1)
+    w2cs[0, :, 0, 3] = torch.linspace(0, 0.3, F, device=dev)
+    Ks = K[None, None].expand(1, F, 3, 3).contiguous()
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=img[None], input_depth=depth[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                    input_intrinsics=K[None], filter_points_threshold=0.05, foreground_masking=True, input_format=["B", "C", "H", "W"])
+    cache.render_cache(w2cs, Ks)
+    torch.cuda.synchronize()
+    tm = ops.HipTimer()
+    tm.start()
+    for _ in range(3):
+        cache.render_cache(w2cs, Ks)
+    tm.stop()
+    per_item = tm.elapsed_ms() / 3 / F
+    gbs = 43.2e6 / (per_item * 1e-3) / 1e9
+    out["roofline_render"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(gbs, 1), frac=round(gbs / 8000.0, 4), ms_per_item=round(per_item, 4),
+                                  workload="cache render (project + splat + mesh occlusion + resolve), 704x1280 items, foreground masking, 43.2 MB algorithmic per item")
+    return out
+
+
 def self_launch_argv(n_gpus: int, argv: list, port: int | None = None) -> list:
     """Command line that runs this script as `n_gpus` ranks of one node (used when bench.py is started bare with --gpus N>1)."""
     if port is None:
@@ -108,6 +160,7 @@ def build_parser():
     ap.add_argument("--blocks", type=int, default=28, help="(debug only) number of DiT blocks; anything but 28 is not the benchmark")
     ap.add_argument("--latent", type=str, default="16,88,160", help="(debug only) latent T,H,W")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tokenizer / renderer roofline entries (a few seconds after the timed region)")
     return ap
 
 
@@ -258,6 +311,11 @@ def main():
             "roofline": roof,
             "roofline_gemm": roof_gemm,
         }
+        if not args.no_extras and world == 1:
+            try:
+                out.update(stage_rooflines(dev))
+            except Exception as e:  # the extras must never hide the measurement
+                out["roofline_extras_error"] = repr(e)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(threads=min(32, os.cpu_count() or 1))  # 32 threads measured fastest on the 2x64-core EPYC host

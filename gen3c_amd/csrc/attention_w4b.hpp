@@ -78,6 +78,10 @@ G3_DEVICE void w4b_step_qk(uint32_t addr, f32x16& s0, f32x16& s1, const f32x16& 
     else if constexpr (!INIT && DMA)
         asm volatile(W4B_M0 W4B_READ W4_WAIT W4B_QK(0) W4_UNIT(1) W4B_DMA W4B_QK(1)
                      : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1) : W4B_A_IN, [m0v] "s"(m0v), [voff] "v"(voff), [sbase] "s"(sbase) : "memory");
+    else if constexpr (INIT && !DMA && EXTRA == 1)
+        asm volatile(W4B_READ W4_WAIT W4B_QK0(0) W4_UNIT(1) W4B_QK0(1) W4B_XA
+                     : W4B_A_OUT, [s0] "=&v"(s0), [s1] "=&v"(s1), [a2] "=&v"(*a2), [b2] "=&v"(*b2), [pe] "+v"(*pe)
+                     : W4B_A_IN, [c0] "v"(c0), [c1] "v"(c1), [x2] "v"(x2), [y2] "v"(y2));
     else if constexpr (INIT && !DMA)
         asm volatile(W4B_READ W4_WAIT W4B_QK0(0) W4_UNIT(1) W4B_QK0(1)
                      : W4B_A_OUT, [s0] "=&v"(s0), [s1] "=&v"(s1) : W4B_A_IN, [c0] "v"(c0), [c1] "v"(c1));
@@ -89,7 +93,7 @@ G3_DEVICE void w4b_step_qk(uint32_t addr, f32x16& s0, f32x16& s1, const f32x16& 
                      : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1), [k2] "=&v"(*k2), [pe] "+v"(*pe) : W4B_A_IN, [a2] "v"(*a2), [b2] "v"(*b2));
     else
         asm volatile(W4B_READ W4_WAIT W4B_QK(0) W4_UNIT(1) W4B_QK(1) : W4B_A_OUT, [s0] "+v"(s0), [s1] "+v"(s1) : W4B_A_IN);
-    static_assert(EXTRA == 0 || (!INIT && !DMA), "w4b_step_qk: extra half units only on plain steps");
+    static_assert(EXTRA == 0 || (!DMA && !(INIT && EXTRA == 2)), "w4b_step_qk: extra half units only on steps without an LDS-DMA piece");
 #undef W4B_A_OUT
 #undef W4B_A_IN
 }
@@ -412,19 +416,21 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
                 using NR = std::integral_constant<int, I + D>;
                 using U = std::integral_constant<int, (XB ? 0 : 4) + I>;
                 constexpr int hu = (U::value >> 2) & 1, pa = 2 * (I & 1);
-                constexpr bool dma = I < 8;
-                constexpr int j = I & 7;
+                // LDS-DMA pieces: steps 0..7 (one per 2 MFMAs), or with XB every second step (one per 4 MFMAs: four waves then ask the vector
+                // memory path for 32 instead of 64 B/clk/CU, its peak - gemm_w4.hpp measured what the bursts cost)
+                constexpr bool dma = XB ? (I & 1) == 0 : I < 8;
+                constexpr int j = XB ? (I >> 1) : (I & 7);
                 const uint32_t m0v = dma ? (j < 4 ? lds_k0 + (uint32_t)(par * KVB * HD * 2 + 256 * j * 16) : lds_v0 + (uint32_t)((par ^ 1) * HD * KVB * 2 + 256 * (j - 4) * 16)) + (uint32_t)wave * 1024u : 0u;
                 uint32_t k1 = 0;
-                if constexpr (XB && I >= 8) {
-                    // half units of pair units 16..19 (all half 0): steps 8, 9 / 12, 13 first halves, steps 10, 11 / 14, 15 second halves
+                if constexpr (XB && (I & 1)) {
+                    // half units of pair units 16..19 (all half 0) on the odd steps: first half of unit 16 + x in step 4 x + 1, second half in 4 x + 3
                     constexpr int ex = (I & 2) ? 2 : 1;
-                    constexpr int xu = 16 + ((I - 8) >> 2) * 2 + (I & 1);
+                    constexpr int xu = 16 + (I >> 2);
                     using XU = std::integral_constant<int, xu>;
                     uint32_t k2 = 0;
-                    w4b_step_qk<I, frag_off(NR{}), true, D, false, false, ex>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
-                                                                              psum[hu][pa], psum[hu][pa + 1], 0u, 0u, nullptr, ta[I & 1], tb[I & 1], ux(XU{}), uy(XU{}), &k2,
-                                                                              &pe[I & 1][ex - 1], &xa[I & 1], &xb[I & 1]);
+                    w4b_step_qk<I, frag_off(NR{}), true, D, (I >> 1) == 0, false, ex>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
+                                                                                      psum[hu][pa], psum[hu][pa + 1], 0u, 0u, nullptr, ta[I & 1], tb[I & 1], ux(XU{}), uy(XU{}), &k2,
+                                                                                      &pe[0][ex - 1], &xa[0], &xb[0]);
                     if constexpr (ex == 2) uput(XU{}, k2);
                 } else {
                     w4b_step_qk<I, frag_off(NR{}), true, D, (I >> 1) == 0, dma>(frag_addr(NR{}), S_next[0][I & 1], S_next[1][I & 1], negm[0], negm[1], ux(U{}), uy(U{}), k1,
