@@ -238,12 +238,54 @@ class ContextParallelAttention:
         be, W, Hg, B, S_local = pending["be"], pending["W"], pending["Hg"], pending["B"], pending["S_local"]
         S_all = S_local * self.world
         out = torch.empty((pending["rows"], pending["H"] * 128), dtype=q.dtype, device=q.device)
-        for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(pending["works"]):
-            wk.wait()
-            wv.wait()
-            vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
-            be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
+        # Lifetime contract: the gathered buffers (kf, vf) and the packed send buffers (_ks, _vs) are consumed by RCCL on its own stream
+        # and by HIP kernels launched through ctypes, which the caching allocator knows nothing about. They stay referenced by `pending`
+        # (held by the caller's frame) until every attention launch below is enqueued on the compute stream; after that, stream order on
+        # the compute stream protects them (a later allocation that reuses the memory is also enqueued there). Do not drop `pending`
+        # entries inside this loop.
+        assert all(len(w) == 6 and w[2] is not None and w[3] is not None for w in pending["works"]), "gathered K / V buffers must stay referenced"
+        works = pending["works"]
+        if not q.is_cuda or len(works) < 2:
+            for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
+                wk.wait()  # makes the compute stream wait for the collective (torch.distributed Work semantics on the NCCL / RCCL backend)
+                wv.wait()
+                vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
+                be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
+            return out
+        # One attention launch per head group covers only H / G heads: 256-row workgroups x 8 heads is 0.9-3.4 rounds of the 256 CUs at
+        # cp = 8..2, so every launch would end with a partly idle chip. The groups are independent, so odd groups go to a second stream:
+        # the next group's workgroups fill the CUs the previous launch has drained. The kernel choice (ops: "attn_variant" 0 = automatic)
+        # looks at one launch; here the chip sees all groups, so the even-fill rule is applied to their sum.
+        from . import ops
+        main = torch.cuda.current_stream(q.device)
+        side = self._side_stream(q.device)
+        total_wg = ((S_local + 255) // 256) * pending["H"] * B
+        rounds = (total_wg + 255) // 256
+        one_wave = S_all > 2048 and S_all % 64 == 0 and total_wg * 100 >= rounds * 256 * 93
+        q_ready = main.record_event()
+        try:
+            if one_wave:
+                ops.set_option("attn_variant", 11)
+            for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
+                st = main if g % 2 == 0 else side
+                with torch.cuda.stream(st):
+                    if st is side:
+                        st.wait_event(q_ready)  # q (and `out`) were produced / allocated on the main stream
+                    wk.wait()  # makes THIS stream wait for the collective (torch.distributed Work semantics on the NCCL / RCCL backend)
+                    wv.wait()
+                    vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
+                    be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
+        finally:
+            if one_wave:
+                ops.set_option("attn_variant", 0)
+            main.wait_stream(side)  # everything enqueued on the main stream from here on (out-projection, buffer reuse) follows both streams
         return out
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = self._side = torch.cuda.Stream(device=device)
+        return st
 
     def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int) -> torch.Tensor:
         return self.finish(q, self.start(k, v, S_local, B, H))
