@@ -69,6 +69,19 @@ def reliable_depth_mask_range_batch(depth: torch.Tensor, window_size: int = 5, r
     return out.bool().reshape(b, 1, h, w)
 
 
+_WINDOW_SPLAT = True  # False: the two-call form (splat into the global accumulator with atomics, then resolve) - kept for A/B and tests
+_WS_CACHE: dict = {}
+
+
+def _window_workspace(nbytes: int, dev) -> torch.Tensor:
+    """Scratch of the window splat (46 KiB per 32x32 source tile and item), cached per device: every call of a render reuses it - the
+    launches are ordered on the stream, and the buffer is never read before it is rewritten."""
+    t = _WS_CACHE.get(dev)
+    if t is None or t.numel() < nbytes:
+        t = _WS_CACHE[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return t
+
+
 def forward_warp(
     frame1: torch.Tensor,
     mask1: Optional[torch.Tensor],
@@ -123,10 +136,17 @@ def forward_warp(
     _lib.check(lib.g3_warp_project_f32(_p(pts, "points"), _p(w2c, "w2c"), _p(K, "K"), _p(m1, "mask1"), _p(z, "z"), _p(flow, "flow"),
                                        _p(cam, "cam"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32), b, h, w, gs, st),
                "g3_warp_project_f32")
-    _lib.check(lib.g3_warp_splat_f32(_p(img, "image"), _p(z, "z"), _p(flow, "flow"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32),
-                                     _p(accum, "accum"), b, h, w, gs, st), "g3_warp_splat_f32")
-    _lib.check(lib.g3_warp_resolve_f32(_p(accum, "accum"), _p(frame, "frame"), _p(mask2, "mask"), _p(depth2, "depth"), b, h, w, st),
-               "g3_warp_resolve_f32")
+    if _WINDOW_SPLAT:
+        # splat + resolve without global atomics: source tiles store their destination windows, a destination-owning pass sums and resolves
+        ws = _window_workspace(int(lib.g3_warp_windows_workspace_bytes(b, h, w)), dev)
+        _lib.check(lib.g3_warp_splat_resolve_f32(_p(img, "image"), _p(z, "z"), _p(flow, "flow"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32),
+                                                 _p(accum, "accum"), ws.data_ptr(), _p(frame, "frame"), _p(mask2, "mask"), _p(depth2, "depth"), b, h, w, gs, st),
+                   "g3_warp_splat_resolve_f32")
+    else:
+        _lib.check(lib.g3_warp_splat_f32(_p(img, "image"), _p(z, "z"), _p(flow, "flow"), _p(maskz, "maskz"), _p(gmax, "gmax", torch.int32),
+                                         _p(accum, "accum"), b, h, w, gs, st), "g3_warp_splat_f32")
+        _lib.check(lib.g3_warp_resolve_f32(_p(accum, "accum"), _p(frame, "frame"), _p(mask2, "mask"), _p(depth2, "depth"), b, h, w, st),
+                   "g3_warp_resolve_f32")
     if foreground_masking:
         assert boundary_mask is not None
         bm = boundary_mask.reshape(b, h, w).to(torch.uint8).contiguous()

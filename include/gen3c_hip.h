@@ -166,6 +166,15 @@ int g3_warp_project_f32(const float* points, const float* w2c, const float* K, c
 int g3_warp_splat_f32(const float* image, const float* z, const float* flow, const float* maskz, const void* group_max,
                       float* accum, int n, int h, int w, int group_size, void* stream);
 int g3_warp_resolve_f32(const float* accum, float* frame, float* mask, float* depth, int n, int h, int w, void* stream);
+
+/* g3_warp_splat_f32 + g3_warp_resolve_f32 in one call without global atomics on the common path: every 32x32 source tile stores its 48x48
+ * destination window into `workspace` and a destination-owning pass sums the overlapping windows in a fixed order and resolves the pixel
+ * (bilinear_splatting + the normalisation / clamp of forward_warp, forward_warp_utils_pytorch.py:576-695,300-334). Same contributions as
+ * the two-call form (whose accumulator still receives the rare out-of-window corners here: zero it first). workspace: g3_warp_windows_workspace_bytes(n, h, w) bytes, 16-byte aligned. depth may be NULL. */
+size_t g3_warp_windows_workspace_bytes(int n, int h, int w);
+int g3_warp_splat_resolve_f32(const float* image, const float* z, const float* flow, const float* maskz, const void* group_max,
+                              float* accum, void* workspace, float* frame, float* mask, float* depth, int n, int h, int w,
+                              int group_size, void* stream);
 int g3_mesh_occlusion_f32(const float* cam_points, const uint8_t* boundary_mask, const float* K, const float* Kinv,
                           float* pts_ds, uint8_t* mask_ds, void* tmin, float* frame, float* mask, float* depth, int n, int h,
                           int w, int factor, void* stream);

@@ -172,3 +172,43 @@ def test_identity_camera_is_idempotent_on_valid_pixels():
     assert float(m.float().mean()) > 0.99
     err = (pix[0, 0, 0] - _t(img, dev)).abs()[:, m]
     assert float(err.max()) < 5e-2 and float(err.mean()) < 1e-3  # max sits on disc silhouettes (fore/background blend)
+
+
+@pytest.mark.parametrize("zoom", [1.0, 0.25])
+def test_window_splat_matches_atomic_splat(zoom):
+    """The default splat (source tiles store their destination windows, a destination-owning pass sums them in tile order and resolves)
+    against the two-call form that adds everything into the global accumulator with atomics: identical masks, colours within the
+    atomics' own order sensitivity (both forms accumulate with fp32 LDS atomics, so neither is bit-reproducible). zoom 0.25 shrinks the image of the scene so
+    that many source tiles land in one destination tile (long overlap lists) and windows cover far more than their own texels."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    h, w = 704, 1280
+    depth, img, K = _scene(h, w)
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, noise_aug_strength=0, input_image=_t(img, dev)[None], input_depth=_t(depth, dev)[None, None],
+                                    input_w2c=torch.eye(4, device=dev)[None], input_intrinsics=_t(K, dev)[None], filter_points_threshold=0.05,
+                                    foreground_masking=False, input_format=["B", "C", "H", "W"])
+    w2cs = np.stack([np.eye(4, dtype=np.float32) for _ in range(4)])
+    w2cs[:, 0, 3] = [0.05, 0.3, -0.4, 0.0]
+    w2cs[3, 2, 3] = 6.0  # pull the camera back: the whole scene shrinks towards the image centre
+    Kz = K.copy()
+    Kz[0, 0] *= zoom
+    Kz[1, 1] *= zoom
+    Ks = _t(Kz, dev)[None, None].expand(1, 4, 3, 3).contiguous()
+    outs = {}
+    for mode in (True, False):
+        renderer._WINDOW_SPLAT = mode
+        try:
+            pix, msk = cache.render_cache(_t(w2cs, dev)[None], Ks, render_depth=False)
+            dep, _ = cache.render_cache(_t(w2cs, dev)[None], Ks, render_depth=True)
+        finally:
+            renderer._WINDOW_SPLAT = True
+        torch.cuda.synchronize()
+        outs.setdefault(mode, []).append((pix.clone(), msk.clone(), dep.clone()))
+    (p1, m1, d1), = outs[True]
+    (p2, m2, d2), = outs[False]
+    assert torch.equal(m1, m2), f"masks differ on {int((m1 != m2).sum())} px"
+    err = (p1 - p2).abs()
+    bad = err > (1e-4 + 1e-3 * p2.abs())
+    print(f"[window vs atomic splat zoom={zoom}] masks equal, coverage {float(m1.mean()):.3f}; colour outliers {int(bad.sum())}/{bad.numel()}, max abs {float(err.max()):.3e}")
+    assert float(bad.float().mean()) < 1e-5 and float(err.max()) < 5e-2
+    torch.testing.assert_close(d1, d2, rtol=1e-3, atol=1e-3)

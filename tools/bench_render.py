@@ -31,8 +31,9 @@ def main():
     w2cs = torch.eye(4, device=dev).repeat(1, F, 1, 1)
     w2cs[0, :, 0, 3] = torch.linspace(0, 0.3, F, device=dev)  # "left" trajectory, movement_distance 0.3
     Ks = t(K)[None, None].expand(1, F, 3, 3).contiguous()
-    for fg, tiled in ((False, 0), (False, 1), (True, 0), (True, 1)):
-        ops.set_option("splat_tiled", tiled)
+    for fg, tiled in ((False, 0), (False, 1), (False, 2), (True, 0), (True, 1), (True, 2)):
+        ops.set_option("splat_tiled", min(tiled, 1))
+        renderer._WINDOW_SPLAT = tiled == 2  # 2: window stores + destination-owned gather/resolve (default)
         cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None],
                                         input_w2c=torch.eye(4, device=dev)[None], input_intrinsics=t(K)[None],
                                         filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
@@ -54,3 +55,4 @@ def main():
 if __name__ == "__main__":
     main()
     ops.set_option("splat_tiled", 1)
+    renderer._WINDOW_SPLAT = True
