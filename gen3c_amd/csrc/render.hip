@@ -254,6 +254,22 @@ __global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __re
 // flagged on 80 % of them) and 76 % of the wave cycles waiting on LDS issue - 20 float atomics per source pixel. Next: merge the contributions
 // of neighbouring lanes (east corners of pixel x = west corners of pixel x + 1, south of row y = north of row y + 1 under a smooth flow)
 // with DPP / permlane before the atomics: 5 instead of 20 per pixel.
+// cross-lane moves for the contribution merge below (gfx9 DPP wavefront shifts, gfx950 v_permlane32_swap): no LDS traffic
+G3_DEVICE int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1: lane i <- lane i - 1 */, 0xf, 0xf, false); }
+G3_DEVICE int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1: lane i <- lane i + 1 */, 0xf, 0xf, false); }
+G3_DEVICE float lane_prev(float v) { return __int_as_float(lane_prev(__float_as_int(v))); }
+G3_DEVICE int from_lane_minus32(int v) {  // lanes 32..63 receive the value of lane - 32 (lanes 0..31 keep their own)
+    int a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a;
+}
+G3_DEVICE int from_lane_plus32(int v) {   // lanes 0..31 receive the value of lane + 32
+    int a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return b;
+}
+G3_DEVICE float from_lane_minus32(float v) { return __int_as_float(from_lane_minus32(__float_as_int(v))); }
+
 __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
                                                                  const float* __restrict__ flow, const float* __restrict__ maskz,
                                                                  const unsigned* __restrict__ group_max, float* __restrict__ accum,
@@ -309,29 +325,78 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     const int ox = org[0], oy = org[1];
     if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
     if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
+    // Accumulate into the window. A wave holds two image rows (lanes 0..31: row y, lanes 32..63: row y + 1). Under a smooth flow the east
+    // corners of pixel x are the west corners of pixel x + 1 and the south corners of row y the north corners of row y + 1, so before any
+    // atomic a lane takes over its left neighbour's east column and (upper half) the lower row's south-west texel when the destination texels
+    // coincide; the donor skips those adds. Same contributions, summed in registers first: ~7 instead of 20 LDS float atomics per pixel, and
+    // those atomics are what bounds this kernel (see above). Every lane runs the cross-lane moves (no divergence around them).
+    const int lane = threadIdx.x & 63;
+    const bool upper = lane >= 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!on[k]) continue;
-        const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
-        const float m = maskz[(int64_t)item * hw + py * w + px];
-        const float dw = wscale[k];
-        const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
-        const int ys[4] = {g[k].fy, g[k].cy, g[k].fy, g[k].cy};
-        const int xs[4] = {g[k].fx, g[k].fx, g[k].cx, g[k].cx};
+        const bool onk = on[k];
+        float nwv[ACC_C], swv[ACC_C], nev[ACC_C], sev[ACC_C];
+        int fx = -1, cx = -2, fy = -3, cy = -4;
+        if (onk) {
+            const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
+            const float m = maskz[(int64_t)item * hw + py * w + px];
+            const float dw = wscale[k];
+            const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float wt = wts[c];
-            const int lx = xs[c] - ox, ly = ys[c] - oy;
-            const float v[ACC_C] = {col[k][0] * wt, col[k][1] * wt, col[k][2] * wt, col[k][3] * wt, wt};
+            for (int e = 0; e < 4; ++e) {
+                nwv[e] = col[k][e] * wts[0]; swv[e] = col[k][e] * wts[1]; nev[e] = col[k][e] * wts[2]; sev[e] = col[k][e] * wts[3];
+            }
+            nwv[4] = wts[0]; swv[4] = wts[1]; nev[4] = wts[2]; sev[4] = wts[3];
+            fx = g[k].fx; cx = g[k].cx; fy = g[k].fy; cy = g[k].cy;
+        } else {
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) nwv[e] = swv[e] = nev[e] = sev[e] = 0.f;
+        }
+        // horizontal: lane i takes lane i - 1's east column when it is this lane's west column
+        const int p_on = lane_prev((int)onk), p_cx = lane_prev(cx), p_fy = lane_prev(fy), p_cy = lane_prev(cy);
+#ifdef G3_AB_SPLAT_NO_H
+        const bool htake = false;
+#else
+        const bool htake = onk && p_on && (lane & 31) != 0 && p_cx == fx && p_fy == fy && p_cy == cy;
+#endif
+#pragma unroll
+        for (int e = 0; e < ACC_C; ++e) {
+            const float pne = lane_prev(nev[e]), pse = lane_prev(sev[e]);
+            if (htake) { nwv[e] += pne; swv[e] += pse; }
+        }
+        const bool east_given = lane_next((int)htake) != 0 && (lane & 31) != 31;
+        // vertical: lane i + 32 takes lane i's south-west texel when it is its own north-west texel
+        const int l_on = from_lane_minus32((int)onk), l_fx = from_lane_minus32(fx), l_cy = from_lane_minus32(cy);
+#ifdef G3_AB_SPLAT_NO_V
+        const bool vtake = false;
+#else
+        const bool vtake = upper && onk && l_on && l_fx == fx && l_cy == fy;
+#endif
+#pragma unroll
+        for (int e = 0; e < ACC_C; ++e) {
+            const float lsw = from_lane_minus32(swv[e]);
+            if (vtake) nwv[e] += lsw;
+        }
+        const int u_take = from_lane_plus32((int)vtake);  // evaluated by EVERY lane: inside `!upper && ...` the swap would run with half the wave masked off
+        const bool sw_given = !upper && u_take != 0;
+        if (!onk) continue;
+        auto add_texel = [&](int x, int y, const float (&v)[ACC_C]) {
+            const int lx = x - ox, ly = y - oy;
             if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
                 float* a = win + (ly * WIN + lx) * ACC_C;
 #pragma unroll
                 for (int e = 0; e < ACC_C; ++e) atomicAdd(a + e, v[e]);
             } else {
-                float* a = acc_item + ((int64_t)ys[c] * aw + xs[c]) * ACC_C;
+                float* a = acc_item + ((int64_t)y * aw + x) * ACC_C;
 #pragma unroll
                 for (int e = 0; e < ACC_C; ++e) unsafeAtomicAdd(a + e, v[e]);
             }
+        };
+        add_texel(fx, fy, nwv);
+        if (!sw_given) add_texel(fx, cy, swv);
+        if (!east_given) {
+            add_texel(cx, fy, nev);
+            add_texel(cx, cy, sev);
         }
     }
     __syncthreads();
