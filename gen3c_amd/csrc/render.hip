@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void warp_splat_kernel(const float* __restrict
 // global atomics, so any flow stays correct. Same contributions as the direct kernel; only the (already order-dependent)
 // summation order differs.
 constexpr int TS = 32;    // source tile edge
-constexpr int WIN = 48;   // destination window edge (46 KiB of LDS)
+constexpr int WIN = 40;   // destination window edge (32 KiB of LDS: 4-5 workgroups per CU; 48: 0.105 vs 0.095 ms per item on the bench scene)
 __global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
                                                                const float* __restrict__ flow, const float* __restrict__ maskz,
                                                                const unsigned* __restrict__ group_max, float* __restrict__ accum,
