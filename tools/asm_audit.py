@@ -1,4 +1,6 @@
-"""Audit of the hand-counted LDS reads in the MW attention kernels (cdna_hip_programming.md 5.7, item 1 / form (ii)).
+"""Audit of the hand-laid inline-asm kernels (attention MW / w4 / w4b, GEMM w4): what the compiler was not told, checked in its output.
+
+Originally: audit of the hand-counted LDS reads in the MW attention kernels (cdna_hip_programming.md 5.7, item 1 / form (ii)).
 
 An inline-asm `ds_read_b128` destination counts as written for the compiler the moment the statement ends, so under register pressure
 hipcc may spill, copy or reuse that register BEFORE the data has landed (silent garbage). This script compiles csrc/attention.hip to
@@ -104,6 +106,52 @@ def audit(asm_text: str):
     return findings
 
 
+def audit_gemm_w4(asm_text: str):
+    """gemm_w4.hpp: inside the K loop (first to last MFMA of the kernel) the accumulators a0..a255 and the fragment buffers v192..v255 belong
+    to the asm statements - no compiler-generated instruction may name them there (the epilogue, behind the loop, is free to); no scratch."""
+    findings, cur, body = [], None, []
+    funcs = {}
+    for ln in asm_text.split("\n"):
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
+        if m:
+            cur = f"gemm_w4<{m.group(2)}>"
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(ln)
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+    for name, v in funcs.items():
+        mf = [i for i, l in enumerate(v) if "v_mfma" in l]
+        if not mf:
+            findings.append(f"{name}: no MFMA found")
+            continue
+        lo, hi = mf[0], mf[-1]
+        in_asm = False
+        for i, l in enumerate(v):
+            t = l.strip()
+            if "ASMSTART" in t:
+                in_asm = True
+                continue
+            if "ASMEND" in t:
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            if t.startswith("scratch_"):
+                findings.append(f"{name}: line {i}: scratch access `{t}`")
+            if in_asm or not (lo <= i <= hi):
+                continue
+            for m in re.finditer(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b", t):
+                kind = m.group(1) or m.group(4)
+                first = int(m.group(2) or m.group(5))
+                last = int(m.group(3) or m.group(5))
+                if kind == "a" or last >= 192:
+                    findings.append(f"{name}: line {i}: compiler-generated `{t}` touches an asm-owned register inside the K loop")
+                    break
+        print(f"{name}: K loop lines {lo}..{hi} audited (asm-owned a0..a255, v192..v255)")
+    return findings
+
+
 def main():
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "attention.s"
@@ -113,6 +161,13 @@ def main():
             print(r.stderr)
             sys.exit(2)
         findings = audit(out.read_text())
+        out2 = Path(td) / "gemm.s"
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
+                            str(ROOT / "gen3c_amd" / "csrc" / "gemm.hip"), "-o", str(out2)], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr)
+            sys.exit(2)
+        findings += audit_gemm_w4(out2.read_text())
     for f in findings:
         print("FINDING:", f)
     print("asm audit:", "clean" if not findings else f"{len(findings)} finding(s)")
