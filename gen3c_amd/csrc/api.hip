@@ -28,6 +28,7 @@ static int env_int(const char* name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 int g3_opt_gemm_regstage = env_int("G3_GEMM_REGSTAGE", 0);
+int g3_opt_attn_xcd_heads = env_int("G3_ATTN_XCD_HEADS", 1);  // w4b: every XCD works on its own heads (1-D grid remap)
 int g3_opt_attn_variant = env_int("G3_ATTN_VARIANT", 0);  // 0 = automatic (attention.hip: flash_attn_launch)
 int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 int g3_opt_gemm_wide_store = env_int("G3_GEMM_WIDE_STORE", 1);
@@ -44,6 +45,7 @@ extern "C" int g3_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_unpinned")) { g3_opt_gemm_unpinned = value; return G3_OK; }
     if (!strcmp(name, "gemm_rowmajor_tiles")) { g3_opt_gemm_rowmajor_tiles = value; return G3_OK; }
     if (!strcmp(name, "attn_variant")) { g3_opt_attn_variant = value; return G3_OK; }
+    if (!strcmp(name, "attn_xcd_heads")) { g3_opt_attn_xcd_heads = value; return G3_OK; }
     return g3_set_error(G3_ERR_ARG, "g3_set_option: unknown option %s", name);
 }
 

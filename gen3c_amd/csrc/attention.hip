@@ -45,6 +45,9 @@ struct AttnParams {
     float scale_log2;  // softmax_scale * log2(e)
     int vt_seg_len;        // > 0: V^T is stored in key segments of this many keys (multiple of 64), segment s at Vt + s*vt_seg_stride
     int64_t vt_seg_stride;  // elements between segments (context parallel: rank-major all-gather of per-rank V^T shards)
+    // w4b with a 1-D grid: workgroup L runs on XCD L % 8 (round-robin dispatch); xcd_heads > 0 gives every XCD its own (batch, head) pairs,
+    // so a head's K / V^T panel is streamed through ONE L2 instead of all eight (grid_q query blocks per pair, n_hb = H * B pairs)
+    int grid_q, n_hb, n_heads, xcd_heads;
 };
 
 G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
@@ -936,6 +939,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.Sq = Sq; p.Skv = Skv;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
+    p.grid_q = 0; p.n_hb = 0; p.n_heads = H; p.xcd_heads = 0;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
@@ -985,6 +989,9 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     hipStream_t st = (hipStream_t)stream;
     if (variant == 10 || variant == 11) {  // w4 with the trimmed issue stream (attention_w4b.hpp)
         dim3 grid4((Sq + W4_BQ - 1) / W4_BQ, H, B);
+        p.grid_q = (int)grid4.x; p.n_hb = H * B; p.n_heads = H;
+        p.xcd_heads = (g3_opt_attn_xcd_heads && (H * B) % 8 == 0) ? 1 : 0;
+        if (p.xcd_heads) grid4 = dim3(grid4.x * H * B, 1, 1);
         if (variant == 11) hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel<true>, grid4, dim3(W4_THREADS), smem, st, p);
         else hipLaunchKernelGGL(flash_attn_fwd_w4b_kernel<false>, grid4, dim3(W4_THREADS), smem, st, p);
         return g3_check_launch("g3_flash_attn_fwd_bf16");

@@ -200,8 +200,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int g = lane >> 5;
-    const int head = blockIdx.y;
-    const int batch = blockIdx.z;
+    int qblk = blockIdx.x, head = blockIdx.y, batch = blockIdx.z;
+    if (p.xcd_heads) {  // 1-D grid: XCD x (= workgroup index % 8) works through the (batch, head) pairs x, x + 8, x + 16, ...
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int hb = xcd + 8 * (slot / p.grid_q);
+        qblk = slot - (slot / p.grid_q) * p.grid_q;
+        head = hb % p.n_heads;
+        batch = hb / p.n_heads;
+    }
 
     const bf16_t* Qb = p.Q + batch * p.q_batch + head * p.q_head;
     const bf16_t* Kb = p.K + batch * p.k_batch + head * p.k_head;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
     // ---- Q fragments of both halves, pre-multiplied by scale * log2(e), into a[128:191]; O accumulators a[0:127] = 0 (as w4)
     static_for<0, 16>([&](auto fc) {
         constexpr int f = decltype(fc)::value, h = f >> 3, ks = f & 7;
-        const int q_idx = blockIdx.x * W4_BQ + wave * 64 + 32 * h + l31;
+        const int q_idx = qblk * W4_BQ + wave * 64 + 32 * h + l31;
         const bool q_ok = q_idx < p.Sq;
         bf16x8 qv = q_ok ? load_bf16x8(Qb + (int64_t)q_idx * p.q_row + 8 * g + 16 * ks) : zero_bf16x8();
 #pragma unroll
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
         constexpr int h = decltype(hc)::value;
         const float extra = (XB && h == 0) ? (pe[0][0] + pe[0][1]) + (pe[1][0] + pe[1][1]) : 0.f;
         const float inv = 1.0f / xor32_sum(((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3])) + extra);
-        const int q_idx = blockIdx.x * W4_BQ + wave * 64 + 32 * h + l31;
+        const int q_idx = qblk * W4_BQ + wave * 64 + 32 * h + l31;
         bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
         static_for<0, 16>([&](auto cc) {  // (d, q4): 4 consecutive output dims per store
             constexpr int d = decltype(cc)::value >> 2, q4 = decltype(cc)::value & 3;

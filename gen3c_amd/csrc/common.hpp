@@ -32,6 +32,7 @@ extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop 
 extern int g3_opt_gemm_pingpong;        // plain K%64==0 GEMMs: 2 (default) / 1 = phase-staggered ping-pong kernel with 2 / 4 phases per K tile, 0 = classic
 extern int g3_opt_gemm_wide_store;      // 1 (default): LDS-transposed full-line epilogue when the operands allow 16-byte rows
 extern int g3_opt_splat_tiled;          // 1 (default): LDS-windowed splat; 0: direct global atomics (A/B)
+extern int g3_opt_attn_xcd_heads;  // 1 (default): w4b attention launches a 1-D grid and gives every XCD its own (batch, head) pairs
 extern int g3_opt_attn_variant;   // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave, 4 (default) = 3 with the softmax scale folded into Q and the running max into the MFMA's C operand
 
 G3_DEVICE float bf16_to_f32(bf16_t v) { return (float)v; }
