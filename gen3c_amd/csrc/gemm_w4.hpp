@@ -35,7 +35,7 @@ template <int R> G3_DEVICE float gw4_acc_read() {
 }
 
 // timing ablations (tools/gemm_ablate_w4.py; results are garbage): -DG3_AB_GW4_ABLATE=<bits>  1: the barrier does not wait for the LDS-DMA,
-// 2: no barrier, 4: no LDS-DMA pieces, 8: no fragment reads
+// 2: no barrier, 4: no LDS-DMA pieces, 8: no fragment reads, 32: no epilogue
 #ifndef G3_AB_GW4_ABLATE
 #define G3_AB_GW4_ABLATE 0
 #endif
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     // wave per SIMD nothing covers the latency of the residual rows, so they were requested before the last K tile (rpre).
     asm volatile("s_nop 7\n\ts_nop 3" ::: GW4_OWNED);  // last MFMA results -> v_accvgpr_read
     __syncthreads();                                     // the operand stages are idle once every wave is past its last fragment read
+    if (G3_AB_GW4_ABLATE & 32) return;  // timing ablation: no epilogue at all
     {
         char* stage = smem_raw + wave * 16384;
         const int n = n0 + wn * 128 + 8 * c2;
