@@ -12,6 +12,13 @@
 //   * LDS-DMA pieces are two instructions inside the step statement (s_mov m0 in front of the step's first MFMA, the load behind it): the
 //     per-lane source offsets are eight loop-invariant VGPRs, the tile's K / V^T bases wave-uniform SGPR pairs advanced by SALU.
 //   * one pair unit per step (four at the tile head, behind the first fragment reads whose latency they cover), so no step carries two.
+//   * hot statements carry NO clobber list (hipcc pads every boundary between two asm statements that share a register - clobbers included -
+//     with an s_nop) and alternate their temporaries / chains / accumulators by step parity; the statements outside the loop keep the lists,
+//     so the AGPR file stays reserved, and tools/asm_audit.py verifies in the generated code that no compiler instruction touches it.
+// Template flag XB (the default kernel, variant 11): the tile barrier moves into the P.V region (in front of step 10) and steps 10..15 read the
+// NEXT tile's first six K fragments across it, so a tile starts with its operands already in the ring; the four head units become half units
+// on the odd steps of region A and the LDS-DMA pieces sit on the even steps (one per 4 MFMAs); with a 1-D grid every XCD works through its
+// own (batch, head) pairs. PMC: 39.9 (XB) vs 41.1 cycles per 32-cycle MFMA.
 // Limits (checked by the launcher, which otherwise runs w4): S_kv a multiple of 64.
 
 #define W4B_RING_AGPRS "a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
