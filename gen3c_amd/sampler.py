@@ -14,6 +14,7 @@ produce (several of them are bf16 because the loop's `sigma` is cast with `.to(*
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, fields
 from typing import Dict, Optional
 
@@ -111,6 +112,8 @@ class Gen3CDenoiser:
         self.state_shape = list(state_shape)
         self.scheduler = EDMEulerScheduler(sigma_max=80, sigma_min=0.0002, sigma_data=sigma_data)
         self._noise_cache: Dict[tuple, torch.Tensor] = {}
+        self._fused_cache = None
+        self.fuse_cond_uncond = os.environ.get("G3_FUSE_COND_UNCOND", "1") != "0"  # one batched forward for the conditional and the unconditional branch of a step (False: two calls)
 
     # ---- host-side scalar algebra, in the reference's dtypes ------------------------------------------------------
     def _coefficients(self, sigma32: torch.Tensor, sigma_next32: torch.Tensor, augment_sigma: float) -> dict:
@@ -126,6 +129,38 @@ class Gen3CDenoiser:
         return dict(c_in_bf16=float(c_in_bf16), c_skip_bf16=float(c_skip_bf16), c_out_bf16=float(c_out_bf16),
                     c_in_step=float(c_in_step), c_skip=float(c_skip), c_out=float(c_out), c_in_aug=float(c_in_aug),
                     sigma=float(sigma32), sigma_next=float(sigma_next32), indicator_off=bool(augment_sigma >= float(s_bf)))
+
+    @staticmethod
+    def _fused_cond_uncond_kwargs(condition: "VideoExtendCondition", uncondition: "VideoExtendCondition", B: int) -> Optional[dict]:
+        """Keyword arguments of one net call over [cond batch | uncond batch], or None when the two conditions cannot share a call
+        (different shapes / flags). Per-sample tensors (leading dim B) are concatenated; broadcast tensors (leading dim 1) and non-tensors
+        must agree and are passed once."""
+        dc, du = condition.to_dict(), uncondition.to_dict()
+        out = {}
+        for k, vc in dc.items():
+            vu = du.get(k)
+            if isinstance(vc, torch.Tensor) and isinstance(vu, torch.Tensor):
+                if vc.shape != vu.shape or vc.dtype != vu.dtype:
+                    return None
+                if k == "gt_latent":  # not an input of the net
+                    out[k] = vc
+                elif vc.dim() >= 1 and vc.shape[0] == B:
+                    out[k] = torch.cat([vc, vu], dim=0)
+                elif vc.dim() >= 1 and vc.shape[0] == 1 and B != 1:
+                    if not torch.equal(vc, vu):
+                        return None
+                    out[k] = vc
+                else:
+                    out[k] = torch.cat([vc, vu], dim=0) if vc.dim() >= 1 else vc
+            elif vc is None and vu is None:
+                out[k] = None
+            elif isinstance(vc, torch.Tensor) or isinstance(vu, torch.Tensor):
+                return None
+            else:
+                if vc != vu:
+                    return None
+                out[k] = vc
+        return out
 
     def _augment_noise(self, shape, device, seed: int) -> torch.Tensor:
         key = (tuple(shape), str(device), seed)
@@ -159,8 +194,25 @@ class Gen3CDenoiser:
         new_xt, new_xt_scaled = ops.edm_prepare_input(xt, gt, noise.contiguous(), ind_t, T, H * W, condition_augment_sigma,
                                                       co["c_in_aug"], co["c_in_bf16"], co["c_in_step"])
         t = sch.timesteps[step_index].to(device=xt.device, dtype=torch.bfloat16)
-        out_c = self.net(x=new_xt_scaled, timesteps=t, **condition.to_dict())
-        out_u = self.net(x=new_xt_scaled, timesteps=t, **uncondition.to_dict())
+        fused = None
+        if self.fuse_cond_uncond:
+            # the conditions are the same objects for all steps of a chunk: build the batched arguments once (this also keeps the DiT's
+            # per-context cross-attention K / V cache valid, which is keyed on the context tensor)
+            key = (B,) + tuple(id(v) for v in condition.to_dict().values()) + tuple(id(v) for v in uncondition.to_dict().values())
+            fc = self._fused_cache
+            if fc is None or fc[0] != key:
+                # (the cache entry keeps the condition objects alive, so the ids in the key cannot be recycled while it is valid)
+                fc = self._fused_cache = (key, self._fused_cond_uncond_kwargs(condition, uncondition, B), condition.to_dict(), uncondition.to_dict())
+            fused = fc[1]
+        if fused is not None:
+            # the conditional and the unconditional forward (model_v2w.py:137-141: two net calls) as ONE forward over a batch of 2 B: every
+            # row is computed exactly as in its own call (GEMM / attention / norm kernels work row-, head- and batch-wise), but the chip sees
+            # launches twice as long - 55 instead of 27.5 rounds of attention workgroups, no half-empty last round - and half as many of them
+            out = self.net(x=torch.cat([new_xt_scaled, new_xt_scaled], dim=0), timesteps=t, **fused)
+            out_c, out_u = out[:B], out[B:]
+        else:
+            out_c = self.net(x=new_xt_scaled, timesteps=t, **condition.to_dict())
+            out_u = self.net(x=new_xt_scaled, timesteps=t, **uncondition.to_dict())
         return ops.edm_cfg_euler_step(out_c, out_u, new_xt, gt, ind_t, T, H * W, guidance, co["c_skip_bf16"], co["c_out_bf16"],
                                       co["c_skip"], co["c_out"], co["sigma"], co["sigma_next"])
 

@@ -151,3 +151,35 @@ def test_full_schedule_trajectory_drift():
     psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=35)
     print(f"[e2e 35 steps] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
     assert psnr >= 33.0
+
+
+def test_fused_cond_uncond_forward_is_bitwise_the_two_call_form():
+    """Gen3CDenoiser.denoise_step runs the conditional and the unconditional branch as ONE batched DiT forward; every row must come out
+    exactly as in its own call (model_v2w.py:137-141 makes two calls)."""
+    import torch
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    from gen3c_amd.sampler import Gen3CDenoiser, VideoExtendCondition, add_condition_video_indicator_and_video_input_mask
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(max_img_h=64, max_img_w=64, max_frames=32, in_channels=81, model_channels=512, num_blocks=2, num_heads=4,
+                                adaln_lora_dim=64, crossattn_emb_channels=256, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=7)
+    B, T, H, W, M = 1, 4, 16, 24, 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    rn = lambda *s, std=1.0: (torch.randn(*s, device=dev, generator=g) * std).to(torch.bfloat16)
+    den = Gen3CDenoiser(net, state_shape=(16, T, H, W))
+    den.scheduler.set_timesteps(35)
+    xt = rn(B, 16, T, H, W, std=float(den.scheduler.init_noise_sigma))
+    gt, pose = rn(B, 16, T, H, W, std=0.5), rn(B, 64, T, H, W, std=0.5)
+    pad = torch.zeros(B, 1, 8 * H, 8 * W, device=dev, dtype=torch.bfloat16)
+
+    def cond(p, ctx):
+        c = VideoExtendCondition(crossattn_emb=ctx, padding_mask=pad, fps=torch.tensor([24.0], device=dev), video_cond_bool=True, condition_video_pose=p)
+        return add_condition_video_indicator_and_video_input_mask(gt, c, 1)
+
+    c, u = cond(pose, rn(B, M, 256, std=0.2)), cond(torch.zeros_like(pose), rn(B, M, 256, std=0.2))
+    outs = []
+    for fuse in (True, False, True):
+        den.fuse_cond_uncond = fuse
+        outs.append(den.denoise_step(xt, 7, c, u, 1.5, 0.001, 1).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
