@@ -273,8 +273,10 @@ def main():
             try:
                 tj = json.loads((ROOT / "profiles" / tf).read_text())
                 same_kernel = tj["kernel"].replace(" ", "").split("<")[0] == kname.replace(" ", "").split("<")[0]
-                if world == 1 and same_kernel and tj["shape"] == {"Sq": m0["Sq"], "Skv": m0["Skv"], "H": m0["H"], "B": m0["B"]}:
-                    traffic = tj["traffic_bytes_per_launch"]
+                js = tj["shape"]
+                if world == 1 and same_kernel and (js["Sq"], js["Skv"], js["H"]) == (m0["Sq"], m0["Skv"], m0["H"]):
+                    # measured at batch js["B"]; a launch over B samples is B independent problems in one grid (per-sample K / V^T panels)
+                    traffic = tj["traffic_bytes_per_launch"] * m0["B"] // js["B"]
                     break
             except Exception:
                 continue
