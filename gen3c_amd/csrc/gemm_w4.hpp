@@ -161,7 +161,6 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     const int wn = wave & 1;   // feature half of the block tile
     const int wm = wave >> 1;  // token half
 
-    static_for<0, 256>([&](auto rc) { gw4_acc_zero<decltype(rc)::value>(); });
 
     // ---- LDS-DMA: wave w stages rows [64 w, 64 w + 64) of both tiles, 8 pieces of 8 rows each; lane -> row 8 q + (lane >> 3), physical chunk
     // lane & 7 holding logical chunk (lane & 7) ^ ((row >> 1) & 7). Per-lane byte offsets from the tile's first row, rows clamped to the matrix.
@@ -211,6 +210,8 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
         for (int q = 0; q < 6; ++q)  // weight pieces 0..5 of tile 1 (what k-step 3 of "tile -1" would have issued)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + 128 + vo_w[q]),
                                              (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
+        // the 256 accumulator writes run while the first tile's LDS-DMA is in flight (one wave per SIMD: nothing else would cover its latency)
+        static_for<0, 256>([&](auto rc) { gw4_acc_zero<decltype(rc)::value>(); });
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
         asm volatile("ds_read_b128 v[192:195], %0\n\tds_read_b128 v[196:199], %0 offset:4096\n\tds_read_b128 v[200:203], %0 offset:8192\n\t"
