@@ -251,9 +251,8 @@ __global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __re
 // still reach - and resolves the pixel in the same pass: no global atomics on the common path and no separate resolve pass over the
 // accumulator (3.85 + 0.21 -> 3.27 + 0.47 ms per 32 items). What bounds both forms is the LDS accumulation itself: rocprofv3 PMC
 // (tools/gpu_pmc_render.sh) shows ~100 LDS-busy cycles per ds_add_f32 wave instruction (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, address conflicts
-// flagged on 80 % of them) and 76 % of the wave cycles waiting on LDS issue - 20 float atomics per source pixel. Next: merge the contributions
-// of neighbouring lanes (east corners of pixel x = west corners of pixel x + 1, south of row y = north of row y + 1 under a smooth flow)
-// with DPP / permlane before the atomics: 5 instead of 20 per pixel.
+// flagged on 80 % of them) and 76 % of the wave cycles waiting on LDS issue - 20 float atomics per source pixel in the plain form. The
+// window kernel therefore merges the contributions of neighbouring pixels in registers first (see its accumulation loop).
 // cross-lane moves for the contribution merge below (gfx9 DPP wavefront shifts, gfx950 v_permlane32_swap): no LDS traffic
 G3_DEVICE int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1: lane i <- lane i - 1 */, 0xf, 0xf, false); }
 G3_DEVICE int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1: lane i <- lane i + 1 */, 0xf, 0xf, false); }
@@ -277,6 +276,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                                                                  int group_size, int tiles_x) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
     __shared__ int org[2];
+    __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
     const int item = blockIdx.y;
     const int hw = h * w;
     const float lmax = __uint_as_float(group_max[item / group_size]);
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     const int64_t slot = (int64_t)item * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
     for (int i = threadIdx.x; i < WIN * WIN * ACC_C; i += 256) win[i] = 0.f;
+    for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
     __syncthreads();
 
     SplatGeom g[4];
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     int mnx = 0x7fffffff, mny = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
+        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);  // a thread owns 4 consecutive rows of one column
         on[k] = false;
         if (py >= h || px >= w) continue;
         const int pix = py * w + px;
@@ -325,78 +326,118 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     const int ox = org[0], oy = org[1];
     if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
     if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
-    // Accumulate into the window. A wave holds two image rows (lanes 0..31: row y, lanes 32..63: row y + 1). Under a smooth flow the east
-    // corners of pixel x are the west corners of pixel x + 1 and the south corners of row y the north corners of row y + 1, so before any
-    // atomic a lane takes over its left neighbour's east column and (upper half) the lower row's south-west texel when the destination texels
-    // coincide; the donor skips those adds. Same contributions, summed in registers first: ~7 instead of 20 LDS float atomics per pixel, and
-    // those atomics are what bounds this kernel (see above). Every lane runs the cross-lane moves (no divergence around them).
+    // Accumulate into the window. A thread owns 4 consecutive rows of one column; a wave 8 rows x 32 columns (lanes 0..31: rows 8 v .. 8 v + 3,
+    // lanes 32..63: rows 8 v + 4 .. 8 v + 7). Under a smooth flow the east corners of pixel x are the west corners of pixel x + 1 and the south
+    // corners of row y the north corners of row y + 1, so before any atomic the contributions that meet in one destination texel are summed in
+    // registers: a lane takes over its left neighbour's east column (DPP wave shift), a row takes over the south-west texel of the row above
+    // it (inside the thread; across the wave's halves with v_permlane32_swap); the donor skips those adds. Same contributions, ~6 instead of
+    // 20 LDS float atomics per pixel - and those atomics are what bounds this kernel (see above). Every lane runs the cross-lane moves.
     const int lane = threadIdx.x & 63;
     const bool upper = lane >= 32;
+    float nwv[4][ACC_C], swv[4][ACC_C], nev[4][ACC_C], sev[4][ACC_C];
+    int fx[4], cx[4], fy[4], cy[4];
+    bool east_given[4], sw_given[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool onk = on[k];
-        float nwv[ACC_C], swv[ACC_C], nev[ACC_C], sev[ACC_C];
-        int fx = -1, cx = -2, fy = -3, cy = -4;
-        if (onk) {
-            const int py = ty0 + (threadIdx.x >> 5) + 8 * k, px = tx0 + (threadIdx.x & 31);
+        fx[k] = -1; cx[k] = -2; fy[k] = -3; cy[k] = -4;
+        if (on[k]) {
+            const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
             const float m = maskz[(int64_t)item * hw + py * w + px];
             const float dw = wscale[k];
             const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                nwv[e] = col[k][e] * wts[0]; swv[e] = col[k][e] * wts[1]; nev[e] = col[k][e] * wts[2]; sev[e] = col[k][e] * wts[3];
+                nwv[k][e] = col[k][e] * wts[0]; swv[k][e] = col[k][e] * wts[1]; nev[k][e] = col[k][e] * wts[2]; sev[k][e] = col[k][e] * wts[3];
             }
-            nwv[4] = wts[0]; swv[4] = wts[1]; nev[4] = wts[2]; sev[4] = wts[3];
-            fx = g[k].fx; cx = g[k].cx; fy = g[k].fy; cy = g[k].cy;
+            nwv[k][4] = wts[0]; swv[k][4] = wts[1]; nev[k][4] = wts[2]; sev[k][4] = wts[3];
+            fx[k] = g[k].fx; cx[k] = g[k].cx; fy[k] = g[k].fy; cy[k] = g[k].cy;
         } else {
 #pragma unroll
-            for (int e = 0; e < ACC_C; ++e) nwv[e] = swv[e] = nev[e] = sev[e] = 0.f;
+            for (int e = 0; e < ACC_C; ++e) nwv[k][e] = swv[k][e] = nev[k][e] = sev[k][e] = 0.f;
         }
         // horizontal: lane i takes lane i - 1's east column when it is this lane's west column
-        const int p_on = lane_prev((int)onk), p_cx = lane_prev(cx), p_fy = lane_prev(fy), p_cy = lane_prev(cy);
-#ifdef G3_AB_SPLAT_NO_H
-        const bool htake = false;
-#else
-        const bool htake = onk && p_on && (lane & 31) != 0 && p_cx == fx && p_fy == fy && p_cy == cy;
-#endif
+        const int p_on = lane_prev((int)on[k]), p_cx = lane_prev(cx[k]), p_fy = lane_prev(fy[k]), p_cy = lane_prev(cy[k]);
+        const bool htake = on[k] && p_on && (lane & 31) != 0 && p_cx == fx[k] && p_fy == fy[k] && p_cy == cy[k];
 #pragma unroll
         for (int e = 0; e < ACC_C; ++e) {
-            const float pne = lane_prev(nev[e]), pse = lane_prev(sev[e]);
-            if (htake) { nwv[e] += pne; swv[e] += pse; }
+            const float pne = lane_prev(nev[k][e]), pse = lane_prev(sev[k][e]);
+            if (htake) { nwv[k][e] += pne; swv[k][e] += pse; }
         }
-        const bool east_given = lane_next((int)htake) != 0 && (lane & 31) != 31;
-        // vertical: lane i + 32 takes lane i's south-west texel when it is its own north-west texel
-        const int l_on = from_lane_minus32((int)onk), l_fx = from_lane_minus32(fx), l_cy = from_lane_minus32(cy);
-#ifdef G3_AB_SPLAT_NO_V
-        const bool vtake = false;
-#else
-        const bool vtake = upper && onk && l_on && l_fx == fx && l_cy == fy;
-#endif
+        const int n_take = lane_next((int)htake);
+        east_given[k] = n_take != 0 && (lane & 31) != 31;
+        sw_given[k] = false;
+    }
+    // vertical, inside the thread: row k + 1 takes row k's south-west texel when it is its own north-west texel
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool vt = on[k] && on[k + 1] && fx[k] == fx[k + 1] && cy[k] == fy[k + 1];
+        if (vt) {
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) nwv[k + 1][e] += swv[k][e];
+            sw_given[k] = true;
+        }
+    }
+    // vertical, across the wave's halves: the first row of lane i + 32 takes the south-west texel of the last row of lane i
+    {
+        const int l_on = from_lane_minus32((int)on[3]), l_fx = from_lane_minus32(fx[3]), l_cy = from_lane_minus32(cy[3]);
+        const bool vtake = upper && on[0] && l_on && l_fx == fx[0] && l_cy == fy[0];
 #pragma unroll
         for (int e = 0; e < ACC_C; ++e) {
-            const float lsw = from_lane_minus32(swv[e]);
-            if (vtake) nwv[e] += lsw;
+            const float lsw = from_lane_minus32(swv[3][e]);
+            if (vtake) nwv[0][e] += lsw;
         }
         const int u_take = from_lane_plus32((int)vtake);  // evaluated by EVERY lane: inside `!upper && ...` the swap would run with half the wave masked off
-        const bool sw_given = !upper && u_take != 0;
-        if (!onk) continue;
-        auto add_texel = [&](int x, int y, const float (&v)[ACC_C]) {
-            const int lx = x - ox, ly = y - oy;
-            if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
-                float* a = win + (ly * WIN + lx) * ACC_C;
+        if (!upper && u_take != 0) sw_given[3] = true;
+    }
+    // After the merge almost every destination texel receives exactly one value: the (merged) north-west contribution of one pixel. LDS float
+    // atomics cost ~6 LDS cycles per LANE (PMC), plain stores 2 cycles per wave instruction, so the texels are first given an owner: every
+    // pixel writes its id to owner[its NW texel] (last writer wins), and after a barrier the pixel that reads its own id back STORES its five
+    // values into the zero-initialised window; everything else - pixels that lost a texel, unmerged south-west / east contributions,
+    // out-of-window corners - follows after a second barrier as atomics, as before.
+    int nw_tex[4];
 #pragma unroll
-                for (int e = 0; e < ACC_C; ++e) atomicAdd(a + e, v[e]);
-            } else {
-                float* a = acc_item + ((int64_t)y * aw + x) * ACC_C;
+    for (int k = 0; k < 4; ++k) {
+        nw_tex[k] = -1;
+        if (!on[k]) continue;
+        const int lx = fx[k] - ox, ly = fy[k] - oy;
+        if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
+            nw_tex[k] = ly * WIN + lx;
+            owner[nw_tex[k]] = k * 256 + (int)threadIdx.x;
+        }
+    }
+    __syncthreads();
+    bool nw_done[4];
 #pragma unroll
-                for (int e = 0; e < ACC_C; ++e) unsafeAtomicAdd(a + e, v[e]);
-            }
-        };
-        add_texel(fx, fy, nwv);
-        if (!sw_given) add_texel(fx, cy, swv);
-        if (!east_given) {
-            add_texel(cx, fy, nev);
-            add_texel(cx, cy, sev);
+    for (int k = 0; k < 4; ++k) {
+        nw_done[k] = false;
+        if (nw_tex[k] >= 0 && owner[nw_tex[k]] == k * 256 + (int)threadIdx.x) {
+            float* a = win + nw_tex[k] * ACC_C;
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) a[e] = nwv[k][e];
+            nw_done[k] = true;
+        }
+    }
+    __syncthreads();
+    auto add_texel = [&](int x, int y, const float (&v)[ACC_C]) {
+        const int lx = x - ox, ly = y - oy;
+        if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
+            float* a = win + (ly * WIN + lx) * ACC_C;
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) atomicAdd(a + e, v[e]);
+        } else {
+            float* a = acc_item + ((int64_t)y * aw + x) * ACC_C;
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) unsafeAtomicAdd(a + e, v[e]);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!on[k]) continue;
+        if (!nw_done[k]) add_texel(fx[k], fy[k], nwv[k]);
+        if (!sw_given[k]) add_texel(fx[k], cy[k], swv[k]);
+        if (!east_given[k]) {
+            add_texel(cx[k], fy[k], nev[k]);
+            add_texel(cx[k], cy[k], sev[k]);
         }
     }
     __syncthreads();
