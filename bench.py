@@ -267,7 +267,7 @@ def main():
         flops_launch = sum(4.0 * m["Sq"] * m["Skv"] * m["H"] * 128 * m["B"] for m, _ in self_attn) / len(self_attn)
         ach = flops_launch / (avg_ms * 1e-3) / 1e12
         m0 = self_attn[0][0]
-        kname = _lib.load().g3_flash_attn_kernel_name(m0["Sq"], m0["Skv"], m0["B"], m0["H"]).decode()
+        kname = m0.get("kernel") or _lib.load().g3_flash_attn_kernel_name(m0["Sq"], m0["Skv"], m0["B"], m0["H"]).decode()
         traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape), if present
         for tf in ("r2_attn_traffic.json", "r1_attn_traffic.json"):
             try:

@@ -233,7 +233,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv:
         _lib.check(lib.g3_flash_attn_fwd_bf16(*common_q, *common_o), "g3_flash_attn_fwd_bf16")
     if timer is not None:
         timer.stop()
-        _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H), timer))
+        # the kernel the launcher picked under the options in force at THIS launch (the context-parallel path sets "attn_variant" per call)
+        _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H, kernel=lib.g3_flash_attn_kernel_name(Sq, Skv, B, H).decode()), timer))
     return out
 
 
