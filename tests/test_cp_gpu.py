@@ -38,3 +38,40 @@ def test_context_parallel_code_path_over_rccl_single_rank():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "[cp_check] OK" in r.stdout
+
+
+def test_cp_attention_two_stream_one_wave_kernel_single_rank():
+    """ContextParallelAttention at a size where the head groups together fill the chip evenly (14 080 local tokens, 32 heads): the groups
+    alternate between two streams and run the one-wave-per-SIMD kernel on segmented V^T. With a 1-rank group the gathered K / V are the
+    local ones, so the result must equal one plain attention call over all heads (same kernel arithmetic per head => bitwise)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gen3c_amd import ops
+    from gen3c_amd.parallel import ContextParallelAttention
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", _free_port())
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        group = dist.new_group([0])
+        S, B, H = 14080, 1, 32
+        g = torch.Generator(device=dev).manual_seed(21)
+        q, k, v = (torch.randn(S * B, H * 128, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+        # gloo moves the (CPU-staged) tensors of the 1-rank all-gather; the kernels and streams are the product ones
+        cpa = ContextParallelAttention(group, head_groups=4)
+        out = cpa(q, k, v, S, B, H)
+        ops.set_option("attn_variant", 11)
+        try:
+            ref = ops.flash_attn(q, k, ops.transpose_v(v, S, B, H), S, S, B, H)
+        finally:
+            ops.set_option("attn_variant", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
