@@ -59,6 +59,7 @@ struct GemmParams {
     ConvGeom cv;
     // EPI_QK_NORM_ROPE: features [0, n_q) are q heads (weight nw_q), [n_q, n_q + n_k) k heads (nw_k), the rest is stored as is
     const bf16_t* nw_q; const bf16_t* nw_k; const float* rope_cos; const float* rope_sin; int n_q, n_k, rope_B; float rms_eps;
+    bf16_t* vt; int64_t vt_ld, vt_batch; int vt_S;  // optional V^T destination of the remaining (v) heads: [B][H_v][128][vt_ld], S valid positions
 };
 
 G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
@@ -805,11 +806,13 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
 
 // Q / K projection with the per-head RMSNorm (+ RoPE) of the reference's Attention.cal_qkv (attention.py:247-280) in the epilogue:
 //   C[:, 0:n_q]         = rope(rmsnorm(A W^T, norm_q))     C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k))     C[:, n_q+n_k:] = A W^T
+// With vt != NULL the remaining (v) heads are written TRANSPOSED into vt [B][H_v][128][vt_ld] (g3_transpose_v_bf16's layout, zero beyond S)
+// and their columns of C are left untouched.
 // Row m is token (s = m / B, b = m % B); cos / sin are fp32 [S][128] (NULL: no RoPE - cross-attention). Same rounding points as
 // g3_gemm_bf16_nt followed by g3_qk_rmsnorm_rope_bf16 in place, which is also what runs when the one-wave-per-SIMD kernel does not apply.
 extern "C" int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
                                          int n_q, int n_k, const void* norm_q, const void* norm_k, const float* cos_table,
-                                         const float* sin_table, int B, float eps, void* stream) {
+                                         const float* sin_table, int B, float eps, void* vt, int64_t vt_ld, void* stream) {
     if (!A || !W || !C) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: null operand");
     if (M <= 0 || N <= 0 || K <= 0 || B <= 0 || (M % B)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: bad shape M=%d N=%d K=%d B=%d", M, N, K, B);
     if (n_q < 0 || n_k < 0 || (n_q % 128) || (n_k % 128) || n_q + n_k > N || (N % 128))
@@ -819,8 +822,13 @@ extern "C" int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void*
     if ((K & 7) || (lda & 7) || (ldw & 7) || (ldc & 7)) return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: K, lda, ldw, ldc must be multiples of 8");
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) || (((uintptr_t)norm_q | (uintptr_t)norm_k) & 15) || (((uintptr_t)cos_table | (uintptr_t)sin_table) & 15))
         return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: operands must be 16-byte aligned");
+    const int S = M / B, n_v = N - n_q - n_k;
+    if (vt && (n_v <= 0 || (vt_ld & 7) || vt_ld < S || ((uintptr_t)vt & 15)))
+        return g3_set_error(G3_ERR_ARG, "g3_gemm_qk_norm_rope_bf16: V^T destination needs v heads, vt_ld %% 8 == 0, vt_ld >= S and 16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const bool fused = (K % BK) == 0 && K >= 2 * BK && !g3_opt_gemm_regstage && g3_opt_gemm_pingpong == 3 && g3_opt_gemm_wide_store;
+    const bool vt_fused = fused && vt && (B == 1 || B == 2 || B == 4);
+    int rc;
     if (fused) {
         GemmParams p;
         p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = (bf16_t*)C; p.ldc = ldc;
@@ -832,12 +840,16 @@ extern "C" int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void*
         p.cv = ConvGeom{};
         p.nw_q = (const bf16_t*)norm_q; p.nw_k = (const bf16_t*)norm_k; p.rope_cos = cos_table; p.rope_sin = sin_table;
         p.n_q = n_q; p.n_k = n_k; p.rope_B = B; p.rms_eps = eps;
-        return launch_w4<EPI_QK_NORM_ROPE>(p, s, "g3_gemm_qk_norm_rope_bf16");
+        p.vt = vt_fused ? (bf16_t*)vt : nullptr; p.vt_ld = vt_ld; p.vt_batch = (int64_t)(n_v / 128) * 128 * vt_ld; p.vt_S = S;
+        rc = launch_w4<EPI_QK_NORM_ROPE>(p, s, "g3_gemm_qk_norm_rope_bf16");
+    } else {
+        rc = g3_gemm_bf16_nt(A, lda, W, ldw, C, ldc, M, N, K, EPI_NONE, nullptr, 1, 0, nullptr, 0, stream);
+        bf16_t* c = (bf16_t*)C;
+        if (rc == G3_OK && n_q) rc = g3_qk_rmsnorm_rope_bf16(c, ldc, norm_q, cos_table, sin_table, c, ldc, S, B, n_q / 128, 128, eps, stream);
+        if (rc == G3_OK && n_k) rc = g3_qk_rmsnorm_rope_bf16(c + n_q, ldc, norm_k, cos_table, sin_table, c + n_q, ldc, S, B, n_k / 128, 128, eps, stream);
     }
-    int rc = g3_gemm_bf16_nt(A, lda, W, ldw, C, ldc, M, N, K, EPI_NONE, nullptr, 1, 0, nullptr, 0, stream);
-    bf16_t* c = (bf16_t*)C;
-    if (rc == G3_OK && n_q) rc = g3_qk_rmsnorm_rope_bf16(c, ldc, norm_q, cos_table, sin_table, c, ldc, M / B, B, n_q / 128, 128, eps, stream);
-    if (rc == G3_OK && n_k) rc = g3_qk_rmsnorm_rope_bf16(c + n_q, ldc, norm_k, cos_table, sin_table, c + n_q, ldc, M / B, B, n_k / 128, 128, eps, stream);
+    // V^T where the epilogue did not write it: the standalone transpose of C's v columns (which the fused form leaves unwritten)
+    if (rc == G3_OK && vt && !vt_fused) rc = g3_transpose_v_bf16((const bf16_t*)C + n_q + n_k, ldc, vt, vt_ld, S, B, n_v / 128, 128, stream);
     return rc;
 }
 

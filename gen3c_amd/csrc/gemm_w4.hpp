@@ -304,12 +304,13 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
         const int n = n0 + wn * 128 + 8 * c2;
         bf16x8 gv1 = zero_bf16x8();
         if (EPI != EPI_NONE && EPI != EPI_GELU && EPI != EPI_QK_NORM_ROPE && p.gate_rows == 1 && n < p.N) gv1 = load_bf16x8(p.gate + n);
-        int qk_type = 0;
+        int qk_type = 0, vt_head = -1;  // vt_head >= 0: this wave's 128 features are v head vt_head and go to V^T instead of C
         bf16x8 nwv = zero_bf16x8();
         if (EPI == EPI_QK_NORM_ROPE) {
             const int nh = n0 + wn * 128;  // first feature of this wave's head
             qk_type = nh < p.n_q ? 1 : (nh < p.n_q + p.n_k ? 2 : 0);
             if (qk_type != 0) nwv = load_bf16x8((qk_type == 1 ? p.nw_q : p.nw_k) + 8 * c2);
+            if (qk_type == 0 && p.vt != nullptr && nh < p.N) vt_head = (nh - p.n_q - p.n_k) >> 7;
         }
         static_for<0, 4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
@@ -341,6 +342,29 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * q4 + e];
                     *reinterpret_cast<f32x4*>(stage + l31 * 512 + (((8 * i + 2 * q4 + g) ^ l31) << 4)) = v;
                 }
+            if (EPI == EPI_QK_NORM_ROPE && vt_head >= 0) {
+                // A v head with a V^T destination (V^T [B][H_v][128][vt_ld], what the attention kernel reads): the staged [32 token rows][128
+                // features] fp32 block is read back COLUMN-wise - a lane gathers 8 consecutive key positions of one feature and batch item
+                // (token rows b + B (8 gq + e), B in {1, 2, 4}) and stores them as one 16-byte piece of the V^T row; 4 lanes cover the 64
+                // contiguous bytes a 32-row block contributes to it. Positions >= S are written as zeros (the V^T tail contract).
+                const int B = p.rope_B, ng = 4 / B;            // groups of 8 key positions per batch item in a 32-row block
+                const int mbase = m0 + wm * 128 + 32 * J;      // multiple of 32, hence of B
+                const int bg = lane & 3, bb = bg / ng, gq = bg - bb * ng;
+                const int s0 = mbase / B + 8 * gq;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int f = 16 * it + (lane >> 2);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int row = bb + B * (8 * gq + e);
+                        const float val = *reinterpret_cast<const float*>(stage + row * 512 + ((((f >> 2) ^ row) << 4) | ((f & 3) << 2)));
+                        o[e] = f32_to_bf16((s0 + e < p.vt_S) ? val : 0.f);
+                    }
+                    if (s0 < p.vt_ld) store_bf16x8(p.vt + (int64_t)bb * p.vt_batch + (int64_t)vt_head * 128 * p.vt_ld + (int64_t)f * p.vt_ld + s0, o);
+                }
+                return;  // this block is done (static_for body)
+            }
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
                 const int row = 4 * s8 + rsub;

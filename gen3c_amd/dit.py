@@ -422,10 +422,10 @@ class VideoExtendGeneralDIT(nn.Module):
                 q = ops.gemm_qk_norm_rope(h, blk["fa_qkv"][:D], D, 0, blk["fa_qn"], None, cos, sin, S, B)
                 o = self._cp_attn.finish(q, pending)
             else:
-                qkv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B)  # [S*B, 3D]
-                q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-                vt = ops.transpose_v(v, S, B, nH)
-                o = ops.flash_attn(q, k, vt, S, S, B, nH)
+                # [S*B, 3D]: q and k normalised + rotated; the v heads go straight into V^T (their columns of qkv stay unwritten)
+                vt = self._vt_buffer(S, B, nH, dev)
+                qkv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B, vt=vt)
+                o = ops.flash_attn(qkv[:, :D], qkv[:, D:2 * D], vt, S, S, B, nH)
             ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- cross attention (unmasked over all M context tokens, general_dit.py:407-410)
             shift, scale, gate = self._modulation(emb, blk["ada"][1], adaln_lora, 3)
@@ -446,6 +446,15 @@ class VideoExtendGeneralDIT(nn.Module):
         h = ops.layernorm_modulate(xs, shift, scale)
         y = ops.gemm_nt(h, P["final_layer.linear.weight"])  # [S*B, p1*p2*t*C]
         return ops.dit_unpatchify(y, B, self.out_channels, T, H, W, pt, ps)
+
+    def _vt_buffer(self, S: int, B: int, H: int, dev) -> torch.Tensor:
+        """V^T [B, H, 128, ceil64(S)] shared by all blocks of all forwards of this shape (each block overwrites positions [0, S); the zero
+        tail the attention kernel relies on is written once, here)."""
+        key = (S, B, H, str(dev))
+        buf = getattr(self, "_vt_cache", None)
+        if buf is None or buf[0] != key:
+            buf = self._vt_cache = (key, torch.zeros((B, H, 128, ops.ceil_to(S, 64)), dtype=torch.bfloat16, device=dev))
+        return buf[1]
 
     def _cross_attention_kv(self, pk, crossattn_emb: torch.Tensor):
         """Per block: K = RMSNorm(to_k(context)) and V^T of the cross-attention (attention.py:247-280 with the T5 context as k/v

@@ -158,9 +158,10 @@ def qk_rmsnorm_rope(x: torch.Tensor, weight: torch.Tensor, cos: Optional[torch.T
 
 def gemm_qk_norm_rope(a: torch.Tensor, w: torch.Tensor, n_q: int, n_k: int, norm_q: Optional[torch.Tensor], norm_k: Optional[torch.Tensor],
                       cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None,
-                      eps: float = 1e-6) -> torch.Tensor:
+                      eps: float = 1e-6, vt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = a @ w^T with per-head RMSNorm (+ RoPE) applied to the feature ranges [0, n_q) (weight norm_q) and [n_q, n_q+n_k) (norm_k)
-    in the GEMM epilogue; the remaining features (v) are stored as they are. Replaces gemm_nt + qk_rmsnorm_rope on views of its output."""
+    in the GEMM epilogue; the remaining features (v) are stored as they are - or, with `vt` ([B, H_v, 128, ld] bf16, ld >= S, tail zero),
+    written transposed into it instead (their columns of `out` then stay unwritten). Replaces gemm_nt + qk_rmsnorm_rope (+ transpose_v)."""
     M, K, lda = _rowmajor2d(a, "a")
     N, Kw, ldw = _rowmajor2d(w, "w")
     assert K == Kw and M == S * B
@@ -177,8 +178,14 @@ def gemm_qk_norm_rope(a: torch.Tensor, w: torch.Tensor, n_q: int, n_k: int, norm
     if _KERNEL_TIMERS is not None and M >= 4096:
         timer = HipTimer()
         timer.start()
+    vtp, vt_ld = 0, 0
+    if vt is not None:
+        n_v = N - n_q - n_k
+        assert n_v > 0 and vt.dim() == 4 and vt.shape[:3] == (B, n_v // 128, 128) and vt.shape[3] >= S and vt.is_contiguous()
+        vtp, vt_ld = _dev(vt, "vt"), vt.shape[3]
     _lib.check(lib.g3_gemm_qk_norm_rope_bf16(_dev(a, "a"), lda, _dev(w, "w"), ldw, _dev(out, "out"), ldc, M, N, K, n_q, n_k,
-                                             _dev(norm_q, "norm_q") if n_q else 0, _dev(norm_k, "norm_k") if n_k else 0, cp, sp, B, eps, _stream()),
+                                             _dev(norm_q, "norm_q") if n_q else 0, _dev(norm_k, "norm_k") if n_k else 0, cp, sp, B, eps, vtp, vt_ld,
+                                             _stream()),
                "g3_gemm_qk_norm_rope_bf16")
     if timer is not None:
         timer.stop()

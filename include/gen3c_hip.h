@@ -104,10 +104,13 @@ int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, c
 /* Q / K(/V) projection with that per-head RMSNorm (+ RoPE) in the GEMM's epilogue (Attention.cal_qkv, attention.py:247-280, as one call):
  *   C[:, 0:n_q] = rope(rmsnorm(A W^T, norm_q)),  C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k)),  C[:, n_q+n_k:N] = A W^T (e.g. v).
  * Row m is token (s = m / B, b = m % B); n_q, n_k, N multiples of 128 (whole heads); cos / sin fp32 [M/B][128] or both NULL. Same
- * rounding points as g3_gemm_bf16_nt followed by g3_qk_rmsnorm_rope_bf16 in place (which is what runs where the fused kernel does not apply). */
+ * rounding points as g3_gemm_bf16_nt followed by g3_qk_rmsnorm_rope_bf16 in place (which is what runs where the fused kernel does not apply).
+ * vt != NULL: the remaining (v) heads are written TRANSPOSED, vt[b][h][d][s] with row length vt_ld >= M/B (g3_transpose_v_bf16's layout:
+ * what g3_flash_attn_fwd_bf16 takes; positions >= M/B written as zeros up to the end of the last 32-row block, the rest of the tail is the
+ * caller's: allocate it zeroed once), and their columns of C are NOT written. */
 int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
                               int n_q, int n_k, const void* norm_q, const void* norm_k, const float* cos_table,
-                              const float* sin_table, int B, float eps, void* stream);
+                              const float* sin_table, int B, float eps, void* vt, int64_t vt_ld, void* stream);
 
 /* Top of a DiT block in ONE pass over x:  x += extra_per_block_pos_emb  (in place; blocks.py:547-548), then
  * out = LayerNorm(x) * (1 + scale) + shift  as g3_layernorm_modulate_bf16. The [S*B, D] embedding is not read from memory: it is

@@ -98,7 +98,7 @@ def test_gemm_nt(M, N, K, epi, regstage):
 
 
 @pytest.mark.parametrize("S,B,H,K,mode", [(512, 1, 4, 512, "qkv"), (300, 2, 2, 256, "qkv"), (1000, 1, 2, 1024, "kv"), (640, 1, 3, 384, "q"), (256, 2, 2, 256, "q_norope"),
-                                          (7040, 1, 32, 4096, "qkv")])
+                                          (7040, 1, 32, 4096, "qkv"), (333, 4, 2, 256, "qkv"), (200, 3, 2, 256, "kv"), (3520, 2, 32, 4096, "qkv")])
 def test_gemm_qk_norm_rope_epilogue_matches_unfused(S, B, H, K, mode):
     """g3_gemm_qk_norm_rope_bf16 (RMSNorm + RoPE in the projection's epilogue, gemm_w4.hpp) against the same projection followed by the
     standalone qk_rmsnorm_rope kernel: identical rounding points; the only difference is the fp32 summation order of the 128 squares."""
@@ -117,6 +117,15 @@ def test_gemm_qk_norm_rope_epilogue_matches_unfused(S, B, H, K, mode):
         ang = torch.randn(S, 128, device=dev, generator=g) * 3
         cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
     fused = ops.gemm_qk_norm_rope(a, w, n_q, n_k, wq if n_q else None, wk if n_k else None, cos, sin, S, B)
+    if n_v:  # the same call with a V^T destination: v heads transposed into it (zero tail kept), their columns of `out` left alone
+        vt = torch.zeros((B, n_v // 128, 128, ops.ceil_to(S, 64)), dtype=torch.bfloat16, device=dev)
+        out2 = torch.full((S * B, N), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm_qk_norm_rope(a, w, n_q, n_k, wq if n_q else None, wk if n_k else None, cos, sin, S, B, out=out2, vt=vt)
+        torch.cuda.synchronize()
+        assert torch.equal(out2[:, :n_q + n_k], fused[:, :n_q + n_k])
+        assert torch.equal(vt, ops.transpose_v(fused[:, n_q + n_k:], S, B, n_v // 128)), "V^T written by the epilogue != transpose of the plain v columns"
+        if K >= 128 and B in (1, 2, 4):
+            assert bool((out2[:, n_q + n_k:] == 7.0).all()), "v columns of C must stay unwritten when V^T is requested"
     ref = ops.gemm_nt(a, w)
     if n_q:
         ops.qk_rmsnorm_rope(ref[:, :n_q], wq, cos, sin, S, B, n_q // 128, out=ref[:, :n_q])
