@@ -24,7 +24,9 @@ struct PosEmbArgs {
     int Hp, Wp, B;
 };
 
-template <bool POS>
+// POS: 0 plain; 1 the position embedding is rebuilt per row from its three axis tables (+ norm); 2 it is read from ONE materialised
+// table pe.pe_t [rows / B][D] (already summed, normalised and rounded: a row then costs one table read instead of three + a division per element)
+template <int POS>
 __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restrict__ x, int64_t ldx,
                                                                  const bf16_t* __restrict__ shift,
                                                                  const bf16_t* __restrict__ scale, int64_t ldmod,
@@ -38,11 +40,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restr
     bf16_t* xr = x + (int64_t)row * ldx;
     const bf16_t *pt = nullptr, *ph = nullptr, *pw = nullptr;
     float pnorm = 1.f;
-    if (POS) {
+    if (POS == 1) {
         const int sidx = row / pe.B;
         const int wq = sidx % pe.Wp, hq = (sidx / pe.Wp) % pe.Hp, tq = sidx / (pe.Wp * pe.Hp);
         pt = pe.pe_t + (int64_t)tq * D; ph = pe.pe_h + (int64_t)hq * D; pw = pe.pe_w + (int64_t)wq * D;
         pnorm = (float)pe.norm[sidx];
+    } else if (POS == 2) {
+        pt = pe.pe_t + (int64_t)(row / pe.B) * D;
     }
 
     float v[LN_MAX_CHUNKS][8];
@@ -52,7 +56,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restr
         const int ch = tid + c * LN_THREADS;
         if (ch < nchunk) {
             bf16x8 t = load_bf16x8(xr + ch * 8);
-            if (POS) {
+            if (POS == 2) {
+                const bf16x8 em = load_bf16x8(pt + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = f32_to_bf16((float)t[e] + (float)em[e]);
+                store_bf16x8(xr + ch * 8, t);
+            } else if (POS == 1) {
                 const bf16x8 a = load_bf16x8(pt + ch * 8), b = load_bf16x8(ph + ch * 8), cw = load_bf16x8(pw + ch * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -306,7 +315,7 @@ extern "C" int g3_layernorm_modulate_bf16(const void* x, int64_t ldx, const void
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: D=%d must be a multiple of 8 and <= %d", D, LN_THREADS * 8 * LN_MAX_CHUNKS);
     if ((ldx & 7) || (ldo & 7) || (ldmod & 7) || mod_rows <= 0)
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: leading dims must be multiples of 8");
-    hipLaunchKernelGGL(ln_modulate_kernel<false>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
+    hipLaunchKernelGGL(ln_modulate_kernel<0>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
                        (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, PosEmbArgs{});
     return g3_check_launch("g3_layernorm_modulate_bf16");
 }
@@ -315,7 +324,8 @@ extern "C" int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const voi
                                                  const void* pos_norm, int T, int Hp, int Wp, int B, const void* shift,
                                                  const void* scale, int64_t ldmod, int mod_rows, void* out, int64_t ldo, int D,
                                                  float eps, void* stream) {
-    if (!x || !pe_t || !pe_h || !pe_w || !pos_norm || !shift || !scale || !out)
+    const bool materialised = pe_t && !pe_h && !pe_w && !pos_norm;  // pe_t is then the finished embedding [T*Hp*Wp][D]
+    if (!x || !pe_t || !shift || !scale || !out || (!materialised && (!pe_h || !pe_w || !pos_norm)))
         return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: null operand");
     if (T <= 0 || Hp <= 0 || Wp <= 0 || B <= 0 || D <= 0 || (D & 7) || D > LN_THREADS * 8 * LN_MAX_CHUNKS)
         return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: bad shape (T=%d Hp=%d Wp=%d B=%d D=%d)", T, Hp, Wp, B, D);
@@ -325,8 +335,12 @@ extern "C" int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const voi
     if (rows64 > 0x7fffffff) return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: too many rows");
     const int rows = (int)rows64;
     PosEmbArgs pe{(const bf16_t*)pe_t, (const bf16_t*)pe_h, (const bf16_t*)pe_w, (const bf16_t*)pos_norm, Hp, Wp, B};
-    hipLaunchKernelGGL(ln_modulate_kernel<true>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
-                       (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, pe);
+    if (materialised)
+        hipLaunchKernelGGL(ln_modulate_kernel<2>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                           (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, pe);
+    else
+        hipLaunchKernelGGL(ln_modulate_kernel<1>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                           (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, pe);
     return g3_check_launch("g3_posemb_layernorm_modulate_bf16");
 }
 

@@ -415,7 +415,11 @@ class VideoExtendGeneralDIT(nn.Module):
         for bi, blk in enumerate(pk["blocks"]):
             # -- self attention; "x = x + extra_per_block_pos_emb" (blocks.py:547-548) rides in the same pass over x as the LayerNorm
             shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
-            h = ops.posemb_layernorm_modulate(xs, pos["pe_t"], pos["pe_h"], pos["pe_w"], pos["norm"], Tp, Hp, Wp, B, shift, scale)
+            if "full" not in pos:  # the finished embedding [S, D], built once per shape with the reference's bf16 rounding points (bf16 tensor ops)
+                pe_sum = (pos["pe_t"][:, None, None, :] + pos["pe_h"][None, :, None, :]) + pos["pe_w"][None, None, :, :]
+                pos["full"] = (pe_sum / pos["norm"].reshape(Tp, Hp, Wp, 1)).reshape(S, D).contiguous()
+                del pe_sum
+            h = ops.posemb_layernorm_modulate(xs, pos["full"], None, None, None, Tp, Hp, Wp, B, shift, scale)
             if self._cp_attn is not None:
                 # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
                 # every output element sees the same K order, so this is bit-identical to the single fused GEMM)

@@ -118,23 +118,28 @@ def layernorm_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor
     return out
 
 
-def posemb_layernorm_modulate(x: torch.Tensor, pe_t: torch.Tensor, pe_h: torch.Tensor, pe_w: torch.Tensor, pos_norm: torch.Tensor, T: int,
-                              Hp: int, Wp: int, B: int, shift: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None,
-                              eps: float = 1e-6) -> torch.Tensor:
+def posemb_layernorm_modulate(x: torch.Tensor, pe_t: torch.Tensor, pe_h: Optional[torch.Tensor], pe_w: Optional[torch.Tensor],
+                              pos_norm: Optional[torch.Tensor], T: int, Hp: int, Wp: int, B: int, shift: torch.Tensor, scale: torch.Tensor,
+                              out: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
     """x [T*Hp*Wp*B, D] += per-block absolute position embedding (IN PLACE), returns LayerNorm(x)*(1+scale)+shift.
-    See g3_posemb_layernorm_modulate_bf16."""
+    Either the three axis tables + norm (the kernel rebuilds every row), or pe_h = pe_w = pos_norm = None and pe_t the finished embedding
+    [T*Hp*Wp, D] (one table read per row). See g3_posemb_layernorm_modulate_bf16."""
     rows, D, ldx = _rowmajor2d(x, "x")
     assert rows == T * Hp * Wp * B
-    for t, n in ((pe_t, T), (pe_h, Hp), (pe_w, Wp)):
-        assert t.dim() == 2 and t.shape[0] >= n and t.shape[1] == D and t.is_contiguous()
-    assert pos_norm.numel() == T * Hp * Wp and pos_norm.is_contiguous()
+    if pe_h is None:
+        assert pe_w is None and pos_norm is None and pe_t.shape == (T * Hp * Wp, D) and pe_t.is_contiguous()
+    else:
+        for t, n in ((pe_t, T), (pe_h, Hp), (pe_w, Wp)):
+            assert t.dim() == 2 and t.shape[0] >= n and t.shape[1] == D and t.is_contiguous()
+        assert pos_norm.numel() == T * Hp * Wp and pos_norm.is_contiguous()
     Bm, Ds, ldmod = _rowmajor2d(shift, "shift")
     assert Ds == D and scale.shape == shift.shape and scale.stride(0) == ldmod
     if out is None:
         out = torch.empty((rows, D), dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.g3_posemb_layernorm_modulate_bf16(_dev(x, "x"), ldx, _dev(pe_t, "pe_t"), _dev(pe_h, "pe_h"), _dev(pe_w, "pe_w"),
-                                                     _dev(pos_norm, "pos_norm"), T, Hp, Wp, B, _dev(shift, "shift"), _dev(scale, "scale"), ldmod, Bm,
+    _lib.check(lib.g3_posemb_layernorm_modulate_bf16(_dev(x, "x"), ldx, _dev(pe_t, "pe_t"), _dev(pe_h, "pe_h") if pe_h is not None else 0,
+                                                     _dev(pe_w, "pe_w") if pe_w is not None else 0, _dev(pos_norm, "pos_norm") if pos_norm is not None else 0,
+                                                     T, Hp, Wp, B, _dev(shift, "shift"), _dev(scale, "scale"), ldmod, Bm,
                                                      _dev(out, "out"), out.stride(0), D, eps, _stream()), "g3_posemb_layernorm_modulate_bf16")
     return out
 

@@ -117,7 +117,8 @@ int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void* W, int64_t
  * rebuilt per row from LearnablePosEmbAxis' three tables pe_t [T,D], pe_h [Hp,D], pe_w [Wp,D] with the reference's bf16 rounding
  * points (position_embedding.py:218-233; normalize, attention.py:108-124):  bf16(bf16(bf16(pe_t+pe_h)+pe_w) / pos_norm[s]),
  * pos_norm [T*Hp*Wp] bf16 = 1e-6 + ||.||_2 / sqrt(D) per token. x: [T*Hp*Wp*B, D] rows (s, b), b fastest. With context
- * parallelism pe_t / pos_norm point at this rank's frames. */
+ * parallelism pe_t / pos_norm point at this rank's frames.  * pe_h == pe_w == pos_norm == NULL: pe_t is the finished (summed, normalised, rounded) embedding [T*Hp*Wp][D] and every row
+ * reads one table row instead of three (what gen3c_amd/dit.py passes: the table is input-independent and built once per shape). */
 int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const void* pe_t, const void* pe_h, const void* pe_w,
                                       const void* pos_norm, int T, int Hp, int Wp, int B, const void* shift, const void* scale,
                                       int64_t ldmod, int mod_rows, void* out, int64_t ldo, int D, float eps, void* stream);

@@ -420,6 +420,11 @@ def test_posemb_layernorm_modulate_equals_the_two_pass_path(T, Hp, Wp, B, D):
     assert torch.equal(x_new, x_ref), f"x differs on {int((x_new != x_ref).sum())} elements"
     assert torch.equal(h, h_ref), f"LN output differs on {int((h != h_ref).sum())} elements"
     assert not torch.equal(x_new, x)
+    # the form the DiT uses: ONE materialised table [S, D] (the embedding above, not repeated over B) instead of the three axis tables
+    x_mat = x.clone()
+    h_mat = ops.posemb_layernorm_modulate(x_mat, emb_n.reshape(S, D).contiguous(), None, None, None, T, Hp, Wp, B, shift, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(x_mat, x_ref) and torch.equal(h_mat, h_ref)
 
 
 def test_errors_are_loud():
