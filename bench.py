@@ -161,7 +161,64 @@ def build_parser():
     ap.add_argument("--latent", type=str, default="16,88,160", help="(debug only) latent T,H,W")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the tokenizer / renderer roofline entries (a few seconds after the timed region)")
+    ap.add_argument("--cp-config", type=str, default="auto",
+                    help="N > 1: 'auto' = time the context-parallel configurations (head groups x attention kernel x collective schedule) on a few blocks "
+                         "before the warm-up and run on the fastest; or 'G,kernel,schedule' e.g. '4,auto,gather_first' to pin one")
     return ap
+
+
+def cp_report(cpa, self_attn, gemms, steps: int, rccl_ranks: int) -> dict:
+    """Diagnosis of the one multi-GPU run the driver makes: where a step's time goes on THIS rank (rank 0), per step. Inputs: the
+    ContextParallelAttention object (its `stats` = (kind, head group, HipTimer) per Work.wait(), `bytes_gathered`), the (meta, ms) lists of the
+    self-attention and GEMM launches of the timed region."""
+    waits = [tm.elapsed_ms() for (_k, _g, tm) in (cpa.stats or [])]
+    steps = max(1, steps)
+    return dict(
+        rccl_ranks=rccl_ranks,
+        attention_ms_per_step=round(sum(ms for _, ms in self_attn) / steps, 2),
+        attention_launches_per_step=len(self_attn) // steps,
+        gemm_ms_per_step=round(sum(ms for _, ms in gemms) / steps, 2),
+        exposed_collective_wait_ms_per_step=round(sum(waits) / steps, 3),
+        collective_waits_per_step=len(waits) // steps,
+        worst_single_wait_ms=round(max(waits), 3) if waits else 0.0,
+        gathered_bytes_per_step=int(cpa.bytes_gathered // steps),
+        note="hipEvent pairs on the launch streams: attention / gemm = sum over launches (head groups alternate between two streams, so "
+             "attention sums can exceed wall time); exposed wait = time a launch stream sat idle in Work.wait() for an all-gather",
+    )
+
+
+CP_TUNE_BLOCKS = 4  # DiT blocks per autotune forward (every block has the same shapes and collectives)
+
+
+def autotune_cp(net, den, xt, cond, uncond, dev, dist):
+    """Pick (head_groups, attention kernel, collective schedule) of ContextParallelAttention by measurement: the driver's multi-GPU run is the
+    only one this code ever gets on real xGMI links, so it tunes itself. Every candidate runs the same denoise step on the first CP_TUNE_BLOCKS
+    blocks (1 untimed + 1 timed, barrier + synchronize on both sides); ranks agree on each time via all_reduce(MAX), so every rank picks the
+    same winner. Untimed by the benchmark (before the warm-up steps); the state `xt` is not advanced."""
+    cands = [(G, kern, sched) for sched in ("gather_first", "local_first") for kern in ("w4b", "wave8") for G in (1, 2, 4, 8)]
+    cpa = net._cp_attn
+    net._tune_blocks = CP_TUNE_BLOCKS
+    table = []
+    try:
+        for (G, kern, sched) in cands:
+            cpa.configure(head_groups=G, kernel=kern, schedule=sched)
+            ms = []
+            for rep in range(2):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                den.denoise_step(xt, 0, cond, uncond, 1.0, 0.001, 1)
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t0) * 1e3)
+            t = torch.tensor([ms[1]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            table.append(dict(head_groups=G, kernel=kern, schedule=sched, ms=round(float(t.item()), 3)))
+    finally:
+        net._tune_blocks = None
+    best = min(table, key=lambda r: r["ms"])
+    cpa.configure(head_groups=best["head_groups"], kernel=best["kernel"], schedule=best["schedule"])
+    return best, table
+
 
 
 def main():
@@ -237,12 +294,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cp_info = None
+    if world > 1:
+        if args.cp_config == "auto":
+            best, table = autotune_cp(net, den, xt, cond, uncond, dev, dist)
+            cp_info = dict(chosen=best, autotune_blocks=CP_TUNE_BLOCKS, autotune_ms=table)
+        else:
+            G, kern, sched = args.cp_config.split(",")
+            net._cp_attn.configure(head_groups=int(G), kernel=kern, schedule=sched)
+            cp_info = dict(chosen=dict(head_groups=int(G), kernel=kern, schedule=sched), autotune_ms=None)
+
     step_id = 0
     for _ in range(args.warmup):
         xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
         step_id += 1
     barrier()
     ops.enable_kernel_timers(True)
+    if world > 1:
+        net._cp_attn.stats = []
+        net._cp_attn.bytes_gathered = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
@@ -268,8 +338,8 @@ def main():
         ach = flops_launch / (avg_ms * 1e-3) / 1e12
         m0 = self_attn[0][0]
         kname = m0.get("kernel") or _lib.load().g3_flash_attn_kernel_name(m0["Sq"], m0["Skv"], m0["B"], m0["H"]).decode()
-        traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same shape), if present
-        for tf in ("r2_attn_traffic.json", "r1_attn_traffic.json"):
+        traffic = traffic_source = None  # HBM bytes per launch: QUOTED from the committed rocprofv3 PMC passes of this kernel at this shape
+        for tf in ("r3_attn_traffic.json", "r2_attn_traffic.json", "r1_attn_traffic.json"):
             try:
                 tj = json.loads((ROOT / "profiles" / tf).read_text())
                 same_kernel = tj["kernel"].replace(" ", "").split("<")[0] == kname.replace(" ", "").split("<")[0]
@@ -277,11 +347,13 @@ def main():
                 if world == 1 and same_kernel and (js["Sq"], js["Skv"], js["H"]) == (m0["Sq"], m0["Skv"], m0["H"]):
                     # measured at batch js["B"]; a launch over B samples is B independent problems in one grid (per-sample K / V^T panels)
                     traffic = tj["traffic_bytes_per_launch"] * m0["B"] // js["B"]
+                    traffic_source = f"profiles/{tf} (rocprofv3 --pmc passes of this kernel, measured at B={js['B']}" + \
+                                     (")" if js["B"] == m0["B"] else f", x{m0['B'] // js['B']} for this launch's batch)") + "; not re-measured in this run"
                     break
             except Exception:
                 continue
         roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches=len(self_attn), avg_launch_ms=round(avg_ms, 3),
                     flops_per_launch=flops_launch)
 
     # second MFMA kernel: the block GEMMs (ping-pong kernel), same live hipEvent timing; reported next to `roofline`
@@ -290,9 +362,14 @@ def main():
     if gemms:
         g_ms = sum(ms for _, ms in gemms)
         g_fl = sum(2.0 * m["M"] * m["N"] * m["K"] for m, _ in gemms)
-        roof_gemm = dict(bound="mfma", kernel="gemm_bf16_nt_w4_kernel<EPI>", achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
+        gm = max(gemms, key=lambda r: r[0]["M"] * r[0]["N"] * r[0]["K"])[0]
+        roof_gemm = dict(bound="mfma", kernel=_lib.load().g3_gemm_kernel_name(gm["M"], gm["N"], gm["K"], gm["epilogue"]).decode(), achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
                          unit="TFLOP/s", frac=round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), launches=len(gemms),
                          total_ms_per_step=round(g_ms / args.steps, 2))
+
+    if world > 1:
+        cp_info.update(cp_report(net._cp_attn, self_attn, gemms, args.steps, dist.get_world_size() if dist.get_backend() == "nccl" else 0))
+        net._cp_attn.stats = None
 
     if rank == 0:
         step_flops = 2 * dit_forward_flops(N_tok, L=args.blocks)
@@ -313,6 +390,8 @@ def main():
             "roofline": roof,
             "roofline_gemm": roof_gemm,
         }
+        if cp_info is not None:
+            out["cp"] = cp_info
         if not args.no_extras and world == 1:
             try:
                 out.update(stage_rooflines(dev))

@@ -27,10 +27,15 @@ SIGNATURES = {
     "g3_gemm_bf16_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, i64, vp, i64, vp],
     "g3_flash_attn_fwd_kvseg_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i64, vp, i64, i64, i64, i32, i32, i32,
                                      i32, i32, f32, vp],
+    "g3_gemm_kernel_name": [i32, i32, i32, i32],
     "g3_gemv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "g3_flash_attn_kernel_name": [i32, i32, i32, i32],
     "g3_flash_attn_fwd_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32,
                                i32, i32, f32, vp],
+    "g3_flash_attn_fwd_ex_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i64, vp, vp, vp, i64, i64, i64, i32, i32, i32,
+                                  i32, i32, f32, i32, vp],
+    "g3_flash_attn_kernel_name_ex": [i32, i32, i32, i32, i32],
+    "g3_attn_merge_partials_bf16": [vp, vp, i32, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32, i32, vp],
     "g3_transpose_v_bf16": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "g3_layernorm_modulate_bf16": [vp, i64, vp, vp, i64, i32, vp, i64, i32, i32, f32, vp],
     "g3_posemb_layernorm_modulate_bf16": [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i32, vp, i64, i32, f32, vp],
@@ -61,7 +66,7 @@ SIGNATURES = {
     "g3_edm_prepare_input_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, vp],
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }
-_RESTYPES = {"g3_last_error": C.c_char_p, "g3_flash_attn_kernel_name": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t,
+_RESTYPES = {"g3_last_error": C.c_char_p, "g3_flash_attn_kernel_name": C.c_char_p, "g3_gemm_kernel_name": C.c_char_p, "g3_flash_attn_kernel_name_ex": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t,
              "g3_warp_windows_workspace_bytes": C.c_size_t}
 
 

@@ -191,6 +191,7 @@ class Session:
                                   num_video_frames=self.chunk, seed=args.seed)
         log_ignored_flags(args)
         self.text = TextEmbedder(args, net.crossattn_emb_channels, dev)
+        self.pipe.text_encoder = self.text  # Gen3cPipeline.generate(prompt="...") - the reference's keyword form - embeds through it
         self.set_prompt(getattr(args, "prompt", None))
         self.rendered_warps: List[torch.Tensor] = []
 
@@ -206,6 +207,12 @@ class Session:
             self._neg = self.text(a.negative_prompt)
         else:
             self._neg = None
+            if a.t5_embedding_path or self.text.source == "t5":
+                # classifier-free guidance is c + g (c - u) even at guidance 1: with u = c the text term cancels. The reference always embeds its
+                # default negative prompt; here that needs a T5 source (--negative_t5_embedding_path or the google-t5/t5-11b checkpoint).
+                self.text.log("[gen3c_amd] WARNING: a text embedding is used but no negative-prompt embedding is available "
+                         "(--negative_t5_embedding_path / --negative_prompt with a T5 checkpoint): the unconditional branch reuses the positive "
+                         "text, so the text contribution to classifier-free guidance vanishes")
 
     @property
     def num_chunks(self) -> int:
@@ -216,7 +223,7 @@ class Session:
         drop their overlapping frame, gen3c_single_image.py:404-405)."""
         if self.args.save_buffer:
             self.rendered_warps.append((renders if first else renders[:, 1:]).clone().cpu())
-        return self.pipe.generate(self._emb, cond_image.to(torch.bfloat16), renders, masks, negative_prompt_embedding=self._neg)
+        return self.pipe.generate_from_embeddings(self._emb, cond_image.to(torch.bfloat16), renders, masks, negative_prompt_embedding=self._neg)
 
     def run_chunks(self, cond_image: torch.Tensor, render_fn: Callable[[int, Optional[torch.Tensor]], tuple]) -> np.ndarray:
         """The chunk loop shared by all entry points. render_fn(start_frame, last_frame01 or None) -> (renders, masks) for frames

@@ -48,6 +48,11 @@ struct AttnParams {
     // w4b with a 1-D grid: workgroup L runs on XCD L % 8 (round-robin dispatch); xcd_heads > 0 gives every XCD its own (batch, head) pairs,
     // so a head's K / V^T panel is streamed through ONE L2 instead of all eight (grid_q query blocks per pair, n_hb = H * B pairs)
     int grid_q, n_hb, n_heads, xcd_heads;
+    // split-KV ("partial") mode, O32 != nullptr: the launch covers only part of a row's keys. Instead of the bf16 output the kernel writes the
+    // row's NORMALISED partial result in fp32 (element strides o_row / o_batch / o_head as O) and LSE[b][h][q] = m + log2(l) (log2 domain,
+    // softmax scale included); g3_attn_merge_partials_bf16 combines the parts of a row: softmax over the union of their keys.
+    float* O32;
+    float* LSE;
 };
 
 G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
@@ -865,6 +870,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
     const float l_tot = xor32_sum(l_run);
     const float inv = 1.0f / l_tot;
+    if (p.O32) {  // split-KV part: fp32 normalised partial + log-sum-exp (wave-uniform branch, after the loop)
+        if (q_ok) {
+            float* orow = p.O32 + (int64_t)blockIdx.z * p.o_batch + (int64_t)blockIdx.y * p.o_head + (int64_t)q_idx * p.o_row;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = accO[d][4 * q4 + e] * inv;
+                    *reinterpret_cast<f32x4*>(orow + 32 * d + 8 * q4 + 4 * g) = o;
+                }
+            if (g == 0) p.LSE[((int64_t)blockIdx.z * p.n_heads + blockIdx.y) * p.Sq + q_idx] = m_run + __builtin_amdgcn_logf(l_tot);
+        }
+        return;
+    }
     if (q_ok) {
         bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
 #pragma unroll
@@ -886,8 +907,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 
 }  // namespace
 
-static int attn_resolve_variant(int Sq, int Skv, int B, int H) {
-    int variant = g3_opt_attn_variant;
+// requested: the per-call kernel choice of the *_ex entry points (0 = the process-wide "attn_variant" option, whose 0 = automatic)
+static int attn_resolve_variant(int Sq, int Skv, int B, int H, int requested = 0) {
+    int variant = requested ? requested : g3_opt_attn_variant;
     if (variant == 0) {
         const long n_wg = (long)((Sq + 255) / 256) * H * B;
         const long rounds = (n_wg + 255) / 256;
@@ -898,9 +920,9 @@ static int attn_resolve_variant(int Sq, int Skv, int B, int H) {
     return variant;
 }
 
-extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) {
+extern "C" const char* g3_flash_attn_kernel_name_ex(int Sq, int Skv, int B, int H, int variant_req) {
     const bool long_ctx = Skv > 2048;
-    switch (attn_resolve_variant(Sq, Skv, B, H)) {
+    switch (attn_resolve_variant(Sq, Skv, B, H, variant_req)) {
         case 1: return long_ctx ? "flash_attn_fwd_kernel<0>" : "flash_attn_fwd_kernel<1>";
         case 2: return long_ctx ? "flash_attn_fwd_v2_kernel<0>" : "flash_attn_fwd_v2_kernel<1>";
         case 3: return long_ctx ? "flash_attn_fwd_v3_kernel<0, 6, 8, false>" : "flash_attn_fwd_v3_kernel<1, 6, 8, false>";
@@ -915,11 +937,15 @@ extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) 
     }
 }
 
+extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) { return g3_flash_attn_kernel_name_ex(Sq, Skv, B, H, 0); }
+
 static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
                              int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
                              int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H,
-                             int head_dim, float softmax_scale, void* stream) {
-    if (!q || !k || !vt || !o) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
+                             int head_dim, float softmax_scale, void* stream, int variant_req = 0, float* o_partial = nullptr, float* lse = nullptr) {
+    if (!q || !k || !vt || (!o && !o_partial)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
+    if ((o_partial != nullptr) != (lse != nullptr)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: o_partial and lse go together");
+    if (o_partial && (((uintptr_t)o_partial & 15) || ((uintptr_t)lse & 3))) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: misaligned o_partial / lse");
     if (head_dim != HD) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: head_dim %d unsupported (128 only)", head_dim);
     if (Sq <= 0 || Skv <= 0 || B <= 0 || H <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: bad shape");
     if ((q_row & 7) || (k_row & 7) || (vt_row & 7) || (o_row & 3) || (q_batch & 7) || (k_batch & 7) || (vt_batch & 7) ||
@@ -940,13 +966,15 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
     p.grid_q = 0; p.n_hb = 0; p.n_heads = H; p.xcd_heads = 0;
+    p.O32 = o_partial; p.LSE = lse;
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
     // 0 (default) = automatic: w4b with the cross-barrier prefetch (11) on long contexts made of whole 64-key tiles whose 256-row workgroups fill the chip's 256 CUs evenly,
     // else 4. Explicit values are kept for A/B runs and tests: 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave,
     // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b, 11 = w4b + cross-barrier prefetch.
-    int variant = attn_resolve_variant(Sq, Skv, B, H);
+    int variant = attn_resolve_variant(Sq, Skv, B, H, variant_req);
+    if (o_partial && variant == 9) variant = 4;  // w4 (ragged S_kv) has no partial epilogue: the 8-wave kernel takes ragged tiles too
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
         // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
@@ -964,6 +992,8 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     }
     if (vt_seg_len > 0 && variant < 3)
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
+    if (o_partial && variant < 3)
+        return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: split-KV partial outputs are implemented by the v3 / w4b kernels only (variant %d chosen)", variant);
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipGetDevice failed");
     {
@@ -1032,4 +1062,86 @@ extern "C" int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_
     if (vt_seg_len <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: vt_seg_len must be positive");
     return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, vt_seg_len, vt_seg_stride, o, o_row,
                              o_batch, o_head, Sq, Skv, B, H, head_dim, softmax_scale, stream);
+}
+
+/* ---- per-call kernel choice + split-KV partial outputs ------------------------------------------------------------------------------------ */
+extern "C" int g3_flash_attn_fwd_ex_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row,
+                                         int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head,
+                                         int vt_seg_len, int64_t vt_seg_stride, void* o, float* o_partial, float* lse, int64_t o_row,
+                                         int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H, int head_dim, float softmax_scale,
+                                         int variant, void* stream) {
+    if (variant < 0 || variant > 11) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: variant %d out of range", variant);
+    if (o && o_partial) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: pass either o (bf16 result) or o_partial + lse, not both");
+    if (o_partial && ((o_row & 3) || (o_batch & 3) || (o_head & 3))) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: o_partial strides must be multiples of 4");
+    return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, vt_seg_len, vt_seg_stride, o, o_row,
+                             o_batch, o_head, Sq, Skv, B, H, head_dim, softmax_scale, stream, variant, o_partial, lse);
+}
+
+namespace {
+// out[row][h*128 + d] = sum_i w_i O_i[row][h*128 + d],  w_i = 2^(lse_i - max_j lse_j) / sum_j 2^(lse_j - max): the softmax over the union of the
+// parts' keys. One thread per 8 output elements (two 16-byte loads per part, one 16-byte store); HBM-streaming.
+constexpr int MERGE_MAX_PARTS = 8;
+struct MergeParams {
+    const float* o[MERGE_MAX_PARTS];
+    const float* lse[MERGE_MAX_PARTS];
+    int n_parts;
+    int64_t p_row, p_batch, p_head;  // strides of the fp32 parts (elements)
+    bf16_t* out; int64_t o_row, o_batch, o_head;
+    int Sq, B, H;
+};
+__global__ __launch_bounds__(256) void attn_merge_partials_kernel(MergeParams p) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (q, b, h, c) with c = 8-element chunk of the head dim, c fastest
+    const int c = (int)(idx & 15);
+    int64_t r = idx >> 4;
+    const int h = (int)(r % p.H); r /= p.H;
+    const int b = (int)(r % p.B);
+    const int64_t qi = r / p.B;
+    if (qi >= p.Sq) return;
+    const int64_t li = ((int64_t)b * p.H + h) * p.Sq + qi;
+    float l[MERGE_MAX_PARTS], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MERGE_MAX_PARTS; ++i)
+        if (i < p.n_parts) { l[i] = p.lse[i][li]; mx = fmaxf(mx, l[i]); }
+    float wsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MERGE_MAX_PARTS; ++i)
+        if (i < p.n_parts) { l[i] = __builtin_amdgcn_exp2f(l[i] - mx); wsum += l[i]; }
+    const float inv = 1.0f / wsum;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t poff = qi * p.p_row + (int64_t)b * p.p_batch + (int64_t)h * p.p_head + 8 * c;
+#pragma unroll
+    for (int i = 0; i < MERGE_MAX_PARTS; ++i)
+        if (i < p.n_parts) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.o[i] + poff);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.o[i] + poff + 4);
+            const float w = l[i] * inv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += w * a[e]; acc[4 + e] += w * bb[e]; }
+        }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(acc[e]);
+    store_bf16x8(p.out + qi * p.o_row + (int64_t)b * p.o_batch + (int64_t)h * p.o_head + 8 * c, o);
+}
+}  // namespace
+
+extern "C" int g3_attn_merge_partials_bf16(const float* const* o_parts, const float* const* lse_parts, int n_parts, int64_t p_row, int64_t p_batch,
+                                           int64_t p_head, void* out, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int B, int H,
+                                           int head_dim, void* stream) {
+    if (!o_parts || !lse_parts || !out) return g3_set_error(G3_ERR_ARG, "g3_attn_merge_partials_bf16: null operand");
+    if (n_parts < 1 || n_parts > MERGE_MAX_PARTS) return g3_set_error(G3_ERR_ARG, "g3_attn_merge_partials_bf16: 1..%d parts", MERGE_MAX_PARTS);
+    if (head_dim != HD || Sq <= 0 || B <= 0 || H <= 0) return g3_set_error(G3_ERR_ARG, "g3_attn_merge_partials_bf16: bad shape");
+    if ((p_row & 3) || (p_batch & 3) || (p_head & 3) || (o_row & 7) || (o_batch & 7) || (o_head & 7) || ((uintptr_t)out & 15))
+        return g3_set_error(G3_ERR_ARG, "g3_attn_merge_partials_bf16: strides / pointers must keep 16-byte alignment");
+    MergeParams p;
+    for (int i = 0; i < MERGE_MAX_PARTS; ++i) {
+        p.o[i] = i < n_parts ? o_parts[i] : nullptr;
+        p.lse[i] = i < n_parts ? lse_parts[i] : nullptr;
+        if (i < n_parts && (!p.o[i] || !p.lse[i] || ((uintptr_t)p.o[i] & 15))) return g3_set_error(G3_ERR_ARG, "g3_attn_merge_partials_bf16: part %d null / misaligned", i);
+    }
+    p.n_parts = n_parts; p.p_row = p_row; p.p_batch = p_batch; p.p_head = p_head;
+    p.out = (bf16_t*)out; p.o_row = o_row; p.o_batch = o_batch; p.o_head = o_head; p.Sq = Sq; p.B = B; p.H = H;
+    const int64_t total = (int64_t)Sq * B * H * 16;
+    hipLaunchKernelGGL(attn_merge_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return g3_check_launch("g3_attn_merge_partials_bf16");
 }

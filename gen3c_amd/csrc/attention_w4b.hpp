@@ -220,6 +220,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
     const bf16_t* Kb = p.K + batch * p.k_batch + head * p.k_head;
     const bf16_t* Vb = p.Vt + batch * p.vt_batch + head * p.vt_head;
     bf16_t* Ob = p.O + batch * p.o_batch + head * p.o_head;
+    // split-KV output pointers: fetched from the kernel arguments HERE (opaque to the optimiser), not by a scalar load hipcc would otherwise
+    // sink to the end of the tile loop, in front of the tail tiles whose lgkmcnt waits are hand-counted (tools/asm_audit.py)
+    float* o32_base = p.O32;
+    float* lse_base = p.LSE;
+    asm volatile("" : "+s"(o32_base), "+s"(lse_base));
 
     // ---- Q fragments of both halves, pre-multiplied by scale * log2(e), into a[128:191]; O accumulators a[0:127] = 0 (as w4)
     static_for<0, 16>([&](auto fc) {
@@ -541,6 +546,21 @@ __global__ __launch_bounds__(W4_THREADS, 1) void flash_attn_fwd_w4b_kernel(AttnP
         const float extra = (XB && h == 0) ? (pe[0][0] + pe[0][1]) + (pe[1][0] + pe[1][1]) : 0.f;
         const float inv = 1.0f / xor32_sum(((psum[h][0] + psum[h][1]) + (psum[h][2] + psum[h][3])) + extra);
         const int q_idx = qblk * W4_BQ + wave * 64 + 32 * h + l31;
+        if (o32_base) {  // split-KV part (see AttnParams): fp32 normalised partial + log-sum-exp in the log2 domain
+            float* prow = o32_base + (int64_t)batch * p.o_batch + (int64_t)head * p.o_head + (int64_t)q_idx * p.o_row;
+            static_for<0, 16>([&](auto cc) {
+                constexpr int d = decltype(cc)::value >> 2, q4 = decltype(cc)::value & 3;
+                constexpr int R = 16 * (4 * h + d) + 4 * q4;
+                f32x4 o;
+                o[0] = w4_acc_read<R + 0>() * inv;
+                o[1] = w4_acc_read<R + 1>() * inv;
+                o[2] = w4_acc_read<R + 2>() * inv;
+                o[3] = w4_acc_read<R + 3>() * inv;
+                if (q_idx < p.Sq) *reinterpret_cast<f32x4*>(prow + 32 * d + 8 * q4 + 4 * g) = o;
+            });
+            if (g == 0 && q_idx < p.Sq) lse_base[((int64_t)batch * p.n_heads + head) * p.Sq + q_idx] = m_run[h] - __builtin_amdgcn_logf(inv);
+            return;
+        }
         bf16_t* orow = Ob + (int64_t)q_idx * p.o_row;
         static_for<0, 16>([&](auto cc) {  // (d, q4): 4 consecutive output dims per store
             constexpr int d = decltype(cc)::value >> 2, q4 = decltype(cc)::value & 3;

@@ -804,6 +804,18 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
     }
 }
 
+// Name of the kernel family g3_gemm_bf16_nt / g3_gemm_qk_norm_rope_bf16 launch for this shape under the options in force (16-byte aligned,
+// 8-element-strided operands assumed - what the DiT passes): for profilers and bench.py's roofline_gemm line, never needed to run the op.
+extern "C" const char* g3_gemm_kernel_name(int M, int N, int K, int epilogue) {
+    (void)M; (void)epilogue;
+    const bool glds = (K % BK) == 0 && !g3_opt_gemm_regstage;
+    const bool wide = g3_opt_gemm_wide_store && !(N & 7);
+    if (glds && g3_opt_gemm_pingpong == 3 && wide && K >= 2 * BK) return "gemm_bf16_nt_w4_kernel<EPI>";
+    if (glds && g3_opt_gemm_pingpong >= 2) return "gemm_bf16_nt_pp_kernel<EPI, 2, false>";
+    if (glds && g3_opt_gemm_pingpong) return "gemm_bf16_nt_pp_kernel<EPI, 4, false>";
+    return glds ? "gemm_bf16_nt_kernel<EPI, true, false, PIN>" : "gemm_bf16_nt_kernel<EPI, false, false, PIN>";
+}
+
 // Q / K projection with the per-head RMSNorm (+ RoPE) of the reference's Attention.cal_qkv (attention.py:247-280) in the epilogue:
 //   C[:, 0:n_q]         = rope(rmsnorm(A W^T, norm_q))     C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k))     C[:, n_q+n_k:] = A W^T
 // With vt != NULL the remaining (v) heads are written TRANSPOSED into vt [B][H_v][128][vt_ld] (g3_transpose_v_bf16's layout, zero beyond S)

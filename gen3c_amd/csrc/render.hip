@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __re
 }
 
 // Window splat (default; gen3c_amd/renderer.py: _WINDOW_SPLAT): the tiled kernel above pays one global atomic per touched texel channel when
-// it flushes its window (~5 M per 704 x 1280 item). Here the flush is a plain, fully coalesced STORE of the window (46 KiB) plus its origin
+// it flushes its window (~5 M per 704 x 1280 item). Here the flush is a plain, fully coalesced STORE of the window (WIN x WIN x 5 floats = 32 KiB at WIN = 40) plus its origin
 // into a per-source-tile workspace, and a second kernel owns the DESTINATION: a workgroup per 32 x 32 output tile lists the source tiles
 // whose windows overlap it (ascending tile order), sums their texels - plus the global accumulator, which only the rare out-of-window corners
 // still reach - and resolves the pixel in the same pass: no global atomics on the common path and no separate resolve pass over the

@@ -34,6 +34,13 @@ class DataType(Enum):
     VIDEO = "video"
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """In-place version counter of `t` for cache keys. Inference tensors (created under torch.inference_mode(), which the reference's
+    pipeline entry points use: world_generation_pipeline.py:1225) do not track one - reading `_version` raises - and cannot be modified
+    in place outside inference mode either; they get the constant -1 and are identified by storage address + object identity."""
+    return -1 if t.is_inference() else t._version
+
+
 def _is_video(data_type) -> bool:
     # accept our enum, the reference's enum, or a plain string
     v = getattr(data_type, "value", data_type)
@@ -133,6 +140,7 @@ class VideoExtendGeneralDIT(nn.Module):
         self._cp_attn: Optional[ContextParallelAttention] = None
         self._tables: Dict[tuple, tuple] = {}
         self._packed = None
+        self._tune_blocks: Optional[int] = None  # bench.py's context-parallel autotune: run only the first n blocks (not a model option)
 
         D, Hd = model_channels, self.head_dim
         kw = dict(device=device, dtype=dtype)
@@ -231,7 +239,7 @@ class VideoExtendGeneralDIT(nn.Module):
     def _weights_key(self) -> tuple:
         """Identity of the current weight set: (storage address, in-place version counter) of every parameter. Any in-place
         update (p.copy_, weight swapping) or re-assignment (load_state_dict(assign=True) on a sub-module) changes it."""
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), tensor_version(p)) for p in self.parameters())
 
     # ------------------------------------------------------------------------------------------------ weight packing
     def _pack(self):
@@ -412,7 +420,7 @@ class VideoExtendGeneralDIT(nn.Module):
         M = crossattn_emb.shape[1]
         nH = self.num_heads
         ca_kv = self._cross_attention_kv(pk, crossattn_emb)
-        for bi, blk in enumerate(pk["blocks"]):
+        for bi, blk in enumerate(pk["blocks"][: self._tune_blocks] if self._tune_blocks else pk["blocks"]):
             # -- self attention; "x = x + extra_per_block_pos_emb" (blocks.py:547-548) rides in the same pass over x as the LayerNorm
             shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
             if "full" not in pos:  # the finished embedding [S, D], built once per shape with the reference's bf16 rounding points (bf16 tensor ops)
@@ -476,7 +484,7 @@ class VideoExtendGeneralDIT(nn.Module):
         (weight set, context tensor) and reused by the 2 x 35 forwards of a chunk (28 x 2 x 4.3 MB per context). The cache key is
         the context tensor's storage address + in-place version counter + shape / dtype; a new prompt tensor or an in-place edit
         rebuilds the entry."""
-        key = (crossattn_emb.data_ptr(), crossattn_emb._version, tuple(crossattn_emb.shape), crossattn_emb.dtype, pk["key"])
+        key = (crossattn_emb.data_ptr(), tensor_version(crossattn_emb), tuple(crossattn_emb.shape), crossattn_emb.dtype, pk["key"])
         cache = self.__dict__.setdefault("_ca_kv_cache", {})
         hit = cache.get(key)
         if hit is not None and hit[0] is crossattn_emb:

@@ -122,7 +122,7 @@ class Gen3cPersistentModel:
         warps = [renders.clone().cpu()] if save_buffer else []
         depths = []
         start_img = self.seeding_image[0:1] if multiframe else self.seeding_image
-        video = self.pipeline.generate(ses._emb, start_img.to(torch.bfloat16), renders, masks, negative_prompt_embedding=ses._neg)
+        video = self.pipeline.generate_from_embeddings(ses._emb, start_img.to(torch.bfloat16), renders, masks, negative_prompt_embedding=ses._neg)
         pred_depth = pred01 = None
         if return_estimated_depths or (num_ar > 1 and not multiframe):
             idx = min(n_chunk - overlap_frames, n_total - 1)
@@ -143,7 +143,7 @@ class Gen3cPersistentModel:
             renders, masks = self.cache.render_cache(w2cs[:, start:end], Ks[:, start:end], start_frame_idx=cache_start)
             if save_buffer:
                 warps.append(renders[:, overlap_frames:].clone().cpu())
-            video_new = self.pipeline.generate(ses._emb, (pred01[None, :, None] * 2 - 1).to(torch.bfloat16), renders, masks,
+            video_new = self.pipeline.generate_from_embeddings(ses._emb, (pred01[None, :, None] * 2 - 1).to(torch.bfloat16), renders, masks,
                                                negative_prompt_embedding=ses._neg)
             video = np.concatenate([video, video_new[overlap_frames:]], axis=0)
             if return_estimated_depths or (it < num_ar - 1 and not multiframe):

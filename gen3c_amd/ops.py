@@ -217,17 +217,27 @@ def transpose_v(v: torch.Tensor, S: int, B: int, H: int, out: Optional[torch.Ten
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv: int, B: int, H: int,
-               out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None, variant: int = 0, partial: bool = False):
     """q: [Sq*B, H*128], k: [Skv*B, H*128] (rows (s,b), b fastest), vt: [B, H, 128, ldvt] -> out [Sq*B, H*128].
     vt may also be 5-D [n_seg, B, H, 128, ld_seg]: V^T in key segments of Skv / n_seg keys each (a rank-major all-gather of
-    per-rank V^T shards, see g3_flash_attn_fwd_kvseg_bf16)."""
+    per-rank V^T shards, see g3_flash_attn_fwd_kvseg_bf16).
+    variant: per-call kernel choice (0 = library option / automatic; 4 = 8-wave kernel, 11 = one-wave-per-SIMD kernel) - no global state.
+    partial=True: the keys are only PART of the rows' keys - returns (o_part fp32 [Sq*B, H*128], lse fp32 [B, H, Sq]) for attn_merge."""
     qr, qw, ldq = _rowmajor2d(q, "q")
     kr, kw, ldk = _rowmajor2d(k, "k")
     assert qr == Sq * B and kr == Skv * B and qw == H * 128 and kw == H * 128
     assert vt.is_contiguous() and vt.dim() in (4, 5) and tuple(vt.shape[-4:-1]) == (B, H, 128)
     ldvt = vt.shape[-1]
-    if out is None:
-        out = torch.empty((Sq * B, H * 128), dtype=torch.bfloat16, device=q.device)
+    o_part = lse = None
+    if partial:
+        assert out is None
+        o_part = torch.empty((Sq * B, H * 128), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+        ldo = o_part.stride(0)
+    else:
+        if out is None:
+            out = torch.empty((Sq * B, H * 128), dtype=torch.bfloat16, device=q.device)
+        ldo = out.stride(0)
     if softmax_scale is None:
         softmax_scale = 1.0 / math.sqrt(128)
     lib = _lib.load()
@@ -235,18 +245,39 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv:
     if _KERNEL_TIMERS is not None:
         timer = HipTimer()
         timer.start()
-    common_q = (_dev(q, "q"), ldq * B, ldq, 128, _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt)
-    common_o = (_dev(out, "out"), out.stride(0) * B, out.stride(0), 128, Sq, Skv, B, H, 128, float(softmax_scale), _stream())
-    if vt.dim() == 5:
-        n_seg = vt.shape[0]
+    n_seg = vt.shape[0] if vt.dim() == 5 else 0
+    if n_seg:
         assert Skv % n_seg == 0
-        _lib.check(lib.g3_flash_attn_fwd_kvseg_bf16(*common_q, Skv // n_seg, B * H * 128 * ldvt, *common_o), "g3_flash_attn_fwd_kvseg_bf16")
-    else:
-        _lib.check(lib.g3_flash_attn_fwd_bf16(*common_q, *common_o), "g3_flash_attn_fwd_bf16")
+    _lib.check(lib.g3_flash_attn_fwd_ex_bf16(_dev(q, "q"), ldq * B, ldq, 128, _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,
+                                             Skv // n_seg if n_seg else 0, B * H * 128 * ldvt if n_seg else 0,
+                                             0 if partial else _dev(out, "out"), _dev(o_part, "o_part", torch.float32) if partial else 0,
+                                             _dev(lse, "lse", torch.float32) if partial else 0, ldo * B, ldo, 128, Sq, Skv, B, H, 128,
+                                             float(softmax_scale), int(variant), _stream()), "g3_flash_attn_fwd_ex_bf16")
     if timer is not None:
         timer.stop()
-        # the kernel the launcher picked under the options in force at THIS launch (the context-parallel path sets "attn_variant" per call)
-        _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H, kernel=lib.g3_flash_attn_kernel_name(Sq, Skv, B, H).decode()), timer))
+        # the kernel the launcher picked for THIS launch (per-call variant, else the library option in force)
+        _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H, partial=partial,
+                                                      kernel=lib.g3_flash_attn_kernel_name_ex(Sq, Skv, B, H, int(variant)).decode()), timer))
+    return (o_part, lse) if partial else out
+
+
+def attn_merge(parts, Sq: int, B: int, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """parts: list of (o_part fp32 [Sq*B, H*128], lse fp32 [B, H, Sq]) from flash_attn(partial=True) over disjoint key sets of the same
+    queries -> bf16 [Sq*B, H*128] = attention over the union of the keys (g3_attn_merge_partials_bf16). `out` may be a column view."""
+    import ctypes as C
+    n = len(parts)
+    assert 1 <= n <= 8
+    ld = parts[0][0].stride(0)
+    for o, l in parts:
+        assert o.shape == (Sq * B, H * 128) and o.stride(1) == 1 and o.stride(0) == ld and l.shape == (B, H, Sq) and l.is_contiguous()
+    if out is None:
+        out = torch.empty((Sq * B, H * 128), dtype=torch.bfloat16, device=parts[0][0].device)
+    orows, ow, ldo = _rowmajor2d(out, "out")
+    assert (orows, ow) == (Sq * B, H * 128)
+    op = (C.c_void_p * n)(*[_dev(o, "o_part", torch.float32) for o, _ in parts])
+    lp = (C.c_void_p * n)(*[_dev(l, "lse", torch.float32) for _, l in parts])
+    _lib.check(_lib.load().g3_attn_merge_partials_bf16(op, lp, n, ld * B, ld, 128, _dev(out, "out"), ldo * B, ldo, 128, Sq, B, H, 128, _stream()),
+               "g3_attn_merge_partials_bf16")
     return out
 
 

@@ -178,12 +178,19 @@ def run_jobs_round_robin(jobs: List[Callable[[], torch.Tensor]], group, shape, d
 # ------------------------------------------------------------------------------------------------------------------
 # context-parallel self-attention
 # ------------------------------------------------------------------------------------------------------------------
+ATTN_KERNELS = {"auto": None, "w4b": 11, "wave8": 4}  # per-call kernel choice of g3_flash_attn_fwd_ex_bf16 ("auto": the even-fill rule below)
+CP_SCHEDULES = ("gather_first", "local_first")
+
+
 def _default_backend():
     from . import ops
     return dict(
         pack=lambda t: t.contiguous(),
         transpose_v=lambda v, S, B, H: ops.transpose_v(v, S, B, H),
-        attention=lambda q, k, vt, Sq, Skv, B, H, out: ops.flash_attn(q, k, vt, Sq, Skv, B, H, out=out),
+        attention=lambda q, k, vt, Sq, Skv, B, H, out, variant=0: ops.flash_attn(q, k, vt, Sq, Skv, B, H, out=out, variant=variant),
+        attention_partial=lambda q, k, vt, Sq, Skv, B, H, variant=0: ops.flash_attn(q, k, vt, Sq, Skv, B, H, variant=variant, partial=True),
+        merge=lambda parts, Sq, B, H, out: ops.attn_merge(parts, Sq, B, H, out=out),
+        timer=ops.HipTimer,
     )
 
 
@@ -191,18 +198,45 @@ class ContextParallelAttention:
     """softmax(Q_local K_all^T) V_all for a token-sharded sequence.
 
     q, k, v: [S_local*B, H*128] (v may be a strided column view). K and V shards are all-gathered head-group by
-    head-group (async, RCCL stream) and consumed by the attention kernel in the same order, so only the first
-    group's exchange is exposed; the rest hides under the attention of earlier groups.
+    head-group (async, RCCL stream) and consumed by the attention kernel in the same order.
 
-    `backend` (dict of callables pack / transpose_v / attention) exists so the sharding + collective schedule can be
-    exercised on CPU with gloo in tests; the product path always uses the HIP kernels.
+    schedule "gather_first": one attention launch per head group over the gathered keys; only the first group's exchange is exposed (behind
+    the Q projection), the rest hides under the attention of earlier groups.
+    schedule "local_first" (what TransformerEngine's ring does behind attn_op.set_context_parallel_group, general_dit.py:540-541: start on the
+    local shard at once): every head group first runs over THIS rank's K / V shard - no collective is waited for - and returns a normalised
+    fp32 partial + log-sum-exp; the remote keys (ranks before / after this one in the gathered buffers) follow as the groups' exchanges land,
+    and g3_attn_merge_partials_bf16 combines the parts. Costs one fp32 round trip of the group's output per part; hides the first exchange.
+
+    kernel: "auto" (the one-wave-per-SIMD kernel when the groups' workgroups together fill the 256 CUs evenly, else the 8-wave kernel), "w4b",
+    "wave8" - passed PER CALL through the C ABI; no process-wide option is touched (launches go out on two streams).
+
+    `backend` (dict of callables) exists so the sharding + collective schedule can be exercised on CPU with gloo in tests; the product path
+    always uses the HIP kernels. `stats` (set to a list to enable): one (kind, head group, HipTimer) per collective wait - the time the launch
+    stream stalled for that exchange - read by bench.py.
     """
 
-    def __init__(self, cp_group, head_groups: int = 4, backend: Optional[dict] = None):
+    def __init__(self, cp_group, head_groups: int = 4, backend: Optional[dict] = None, schedule: str = "gather_first", kernel: str = "auto"):
+        assert schedule in CP_SCHEDULES and kernel in ATTN_KERNELS
         self.group = cp_group
         self.world = dist.get_world_size(cp_group)
+        self.rank = dist.get_rank(cp_group)
         self.head_groups = head_groups
         self.backend = backend
+        self.schedule = schedule
+        self.kernel = kernel
+        self.stats = None
+        self.bytes_gathered = 0  # received from the other ranks since construction / the last reset (bench.py's "cp" object)
+
+    def configure(self, head_groups: Optional[int] = None, schedule: Optional[str] = None, kernel: Optional[str] = None):
+        if head_groups is not None:
+            self.head_groups = int(head_groups)
+        if schedule is not None:
+            assert schedule in CP_SCHEDULES
+            self.schedule = schedule
+        if kernel is not None:
+            assert kernel in ATTN_KERNELS
+            self.kernel = kernel
+        return self
 
     def start(self, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int):
         """Issue the K / V all-gathers of every head group (async). Call as soon as K and V exist: whatever the caller
@@ -231,8 +265,33 @@ class ContextParallelAttention:
                 vs = be["pack"](v[:, g * W:(g + 1) * W])
                 vf = torch.empty((self.world * rows, W), dtype=v.dtype, device=v.device)
             wv = dist.all_gather_into_tensor(vf, vs, group=self.group, async_op=True)
+            self.bytes_gathered += (self.world - 1) * (ks.numel() * ks.element_size() + vs.numel() * vs.element_size())
             works.append((wk, wv, kf, vf, ks, vs))
         return dict(works=works, S_local=S_local, B=B, H=H, Hg=Hg, W=W, rows=rows, be=be, segmented=segmented)
+
+    def _variant(self, S_local: int, S_all: int, B: int, H: int) -> int:
+        """Kernel for every launch of this layer. One launch per head group covers only H / G heads - 0.9 to 3.4 rounds of the 256 CUs at
+        cp = 8..2 - but the groups run back to back on two streams, so the chip sees their SUM: the one-wave-per-SIMD kernel's even-fill rule
+        (attention.hip: attn_resolve_variant) is applied to all H heads."""
+        forced = ATTN_KERNELS[self.kernel]
+        if forced is not None:
+            return forced if S_all % 64 == 0 else 4
+        total_wg = ((S_local + 255) // 256) * H * B
+        rounds = (total_wg + 255) // 256
+        return 11 if (S_all > 2048 and S_all % 64 == 0 and total_wg * 100 >= rounds * 256 * 93) else 4
+
+    def _wait(self, be, g: int, *works):
+        """Work.wait() makes the CURRENT stream wait for the collective (torch.distributed semantics on the NCCL / RCCL backend). With stats
+        enabled an event pair brackets it: elapsed = how long this stream had nothing to run because the exchange had not landed yet."""
+        tm = None
+        if self.stats is not None and "timer" in be:
+            tm = be["timer"]()
+            tm.start()
+        for w in works:
+            w.wait()
+        if tm is not None:
+            tm.stop()
+            self.stats.append(("wait", g, tm))
 
     def finish(self, q: torch.Tensor, pending: dict) -> torch.Tensor:
         be, W, Hg, B, S_local = pending["be"], pending["W"], pending["Hg"], pending["B"], pending["S_local"]
@@ -245,40 +304,53 @@ class ContextParallelAttention:
         # entries inside this loop.
         assert all(len(w) == 6 and w[2] is not None and w[3] is not None for w in pending["works"]), "gathered K / V buffers must stay referenced"
         works = pending["works"]
-        if not q.is_cuda or len(works) < 2:
-            for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
-                wk.wait()  # makes the compute stream wait for the collective (torch.distributed Work semantics on the NCCL / RCCL backend)
-                wv.wait()
-                vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
-                be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
-            return out
-        # One attention launch per head group covers only H / G heads: 256-row workgroups x 8 heads is 0.9-3.4 rounds of the 256 CUs at
-        # cp = 8..2, so every launch would end with a partly idle chip. The groups are independent, so odd groups go to a second stream:
-        # the next group's workgroups fill the CUs the previous launch has drained. The kernel choice (ops: "attn_variant" 0 = automatic)
-        # looks at one launch; here the chip sees all groups, so the even-fill rule is applied to their sum.
-        from . import ops
-        main = torch.cuda.current_stream(q.device)
-        side = self._side_stream(q.device)
-        total_wg = ((S_local + 255) // 256) * pending["H"] * B
-        rounds = (total_wg + 255) // 256
-        one_wave = S_all > 2048 and S_all % 64 == 0 and total_wg * 100 >= rounds * 256 * 93
-        q_ready = main.record_event()
+        variant = self._variant(S_local, S_all, B, pending["H"]) if q.is_cuda else 0
+        local_first = self.schedule == "local_first" and pending["segmented"] and self.world > 1 and "attention_partial" in be
+        two_streams = q.is_cuda and len(works) >= 2
+        main = side = q_ready = None
+        if two_streams:
+            # The groups are independent, so odd groups go to a second stream: the next group's workgroups fill the CUs the previous launch has drained.
+            main = torch.cuda.current_stream(q.device)
+            side = self._side_stream(q.device)
+            q_ready = main.record_event()
+
+        def on_stream(g):
+            st = main if (not two_streams or g % 2 == 0) else side
+            ctx = torch.cuda.stream(st) if two_streams else _NullCtx()
+            return st, ctx
+
         try:
-            if one_wave:
-                ops.set_option("attn_variant", 11)
+            local_parts = {}
+            if local_first:
+                # phase 1: every group over this rank's own shard - the packed K columns and the local V^T that were SENT (w[4], w[5]); no wait
+                for g, (wk, wv, kf, vf, ks, vs) in enumerate(works):
+                    st, ctx = on_stream(g)
+                    with ctx:
+                        if two_streams and st is side:
+                            st.wait_event(q_ready)  # q (and `out`) were produced / allocated on the main stream
+                        local_parts[g] = be["attention_partial"](q[:, g * W:(g + 1) * W], ks, vs.reshape(1, B, Hg, 128, -1), S_local, S_local, B, Hg, variant=variant)
             for g, (wk, wv, kf, vf, _ks, _vs) in enumerate(works):
-                st = main if g % 2 == 0 else side
-                with torch.cuda.stream(st):
-                    if st is side:
-                        st.wait_event(q_ready)  # q (and `out`) were produced / allocated on the main stream
-                    wk.wait()  # makes THIS stream wait for the collective (torch.distributed Work semantics on the NCCL / RCCL backend)
-                    wv.wait()
-                    vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
-                    be["attention"](q[:, g * W:(g + 1) * W], kf, vt, S_local, S_all, B, Hg, out[:, g * W:(g + 1) * W])
+                st, ctx = on_stream(g)
+                with ctx:
+                    if two_streams and st is side and not local_first:
+                        st.wait_event(q_ready)
+                    self._wait(be, g, wk, wv)
+                    qg, og = q[:, g * W:(g + 1) * W], out[:, g * W:(g + 1) * W]
+                    if local_first:
+                        # phase 2: the other ranks' keys = the row blocks / V^T segments before and after this rank's in the gathered buffers
+                        parts = [local_parts[g]]
+                        vseg = vf.view(self.world, B, Hg, 128, -1)
+                        rows = pending["rows"]
+                        for (r0, r1) in ((0, self.rank), (self.rank + 1, self.world)):
+                            if r1 > r0:
+                                parts.append(be["attention_partial"](qg, kf[r0 * rows:r1 * rows], vseg[r0:r1], S_local, (r1 - r0) * S_local, B, Hg, variant=variant))
+                        be["merge"](parts, S_local, B, Hg, og)
+                    else:
+                        vt = vf.view(self.world, B, Hg, 128, -1) if pending["segmented"] else be["transpose_v"](vf, S_all, B, Hg)
+                        be["attention"](qg, kf, vt, S_local, S_all, B, Hg, og, variant=variant)
         finally:
-            if one_wave:
-                ops.set_option("attn_variant", 0)
-            main.wait_stream(side)  # everything enqueued on the main stream from here on (out-projection, buffer reuse) follows both streams
+            if two_streams:
+                main.wait_stream(side)  # everything enqueued on the main stream from here on (out-projection, buffer reuse) follows both streams
         return out
 
     def _side_stream(self, device):
@@ -289,3 +361,11 @@ class ContextParallelAttention:
 
     def __call__(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, S_local: int, B: int, H: int) -> torch.Tensor:
         return self.finish(q, self.start(k, v, S_local, B, H))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

@@ -197,14 +197,41 @@ class Gen3cPipeline:
     T5 embeddings and the rendered 3D-cache buffers, returns the uint8 video."""
 
     def __init__(self, model: DiffusionGen3CModel, guidance: float = 1.0, num_steps: int = 35, height: int = 704, width: int = 1280,
-                 fps: int = 24, num_video_frames: int = 121, seed: int = 1):
+                 fps: int = 24, num_video_frames: int = 121, seed: int = 1, text_encoder=None):
+        """text_encoder: callable str -> T5 embedding [1,512,1024] (cli_common.TextEmbedder; T5-11B itself is an input of the path).
+        Only generate() with string prompts needs it."""
         self.model, self.guidance, self.num_steps = model, guidance, num_steps
         self.height, self.width, self.fps, self.num_video_frames, self.seed = height, width, fps, num_video_frames, seed
+        self.text_encoder = text_encoder
 
     @torch.no_grad()
-    def generate(self, prompt_embedding: torch.Tensor, image: torch.Tensor, rendered_warp_images: torch.Tensor,
-                 rendered_warp_masks: torch.Tensor, negative_prompt_embedding: Optional[torch.Tensor] = None,
-                 xt: Optional[torch.Tensor] = None) -> np.ndarray:
+    def generate(self, prompt, image_path, rendered_warp_images: torch.Tensor, rendered_warp_masks: torch.Tensor,
+                 negative_prompt=None, xt: Optional[torch.Tensor] = None):
+        """The reference's Gen3cPipeline.generate seam (gen3c_pipeline.py:108-184; called with exactly these keywords by
+        gen3c_single_image.py:366-372, 411-417): returns (uint8 video [T,H,W,3], prompt).
+          prompt / negative_prompt: str (embedded by `text_encoder`, world_generation_pipeline.py:188-231) or a ready T5 embedding tensor;
+          image_path: path of the conditioning image, or - as the reference's autoregressive loop passes it - a [1,3,1,H,W] tensor in [-1,1].
+        The guardrail / prompt-upsampler steps of the reference are control plane and not part of this path."""
+        def embed(p_):
+            if p_ is None or isinstance(p_, torch.Tensor):
+                return p_
+            if self.text_encoder is None:
+                raise RuntimeError("Gen3cPipeline.generate got a string prompt but no text_encoder: construct the pipeline with "
+                                   "text_encoder=cli_common.TextEmbedder(...) or pass the T5 embedding tensor")
+            return self.text_encoder(p_)
+        if isinstance(image_path, str):
+            from .gen3c_single_image import load_condition_image
+            image = load_condition_image(image_path, self.height, self.width)
+        else:
+            image = image_path
+        video = self.generate_from_embeddings(embed(prompt), image, rendered_warp_images, rendered_warp_masks,
+                                              negative_prompt_embedding=embed(negative_prompt) if negative_prompt else None, xt=xt)
+        return video, prompt
+
+    @torch.no_grad()
+    def generate_from_embeddings(self, prompt_embedding: torch.Tensor, image: torch.Tensor, rendered_warp_images: torch.Tensor,
+                                 rendered_warp_masks: torch.Tensor, negative_prompt_embedding: Optional[torch.Tensor] = None,
+                                 xt: Optional[torch.Tensor] = None) -> np.ndarray:
         """image: [1,3,1,H,W] in [-1,1] (the reference reads uint8/128-1, inference_utils.py:648);
         rendered_warp_images [1,121,N,3,H,W], rendered_warp_masks [1,121,N,1,H,W] (Cache3D.render_cache).
         -> uint8 [121,H,W,3]."""

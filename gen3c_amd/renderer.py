@@ -74,7 +74,7 @@ _WS_CACHE: dict = {}
 
 
 def _window_workspace(nbytes: int, dev) -> torch.Tensor:
-    """Scratch of the window splat (46 KiB per 32x32 source tile and item), cached per device: every call of a render reuses it - the
+    """Scratch of the window splat (one 40x40x5-float window = 32 KiB per 32x32 source tile and item; sized by g3_warp_windows_workspace_bytes), cached per device: every call of a render reuses it - the
     launches are ordered on the stream, and the buffer is never read before it is rewritten."""
     t = _WS_CACHE.get(dev)
     if t is None or t.numel() < nbytes:

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dit import DataType
+from .dit import DataType, tensor_version
 from .parallel import cat_outputs_cp, split_inputs_cp
 
 
@@ -198,7 +198,11 @@ class Gen3CDenoiser:
         if self.fuse_cond_uncond:
             # the conditions are the same objects for all steps of a chunk: build the batched arguments once (this also keeps the DiT's
             # per-context cross-attention K / V cache valid, which is keyed on the context tensor)
-            key = (B,) + tuple(id(v) for v in condition.to_dict().values()) + tuple(id(v) for v in uncondition.to_dict().values())
+            # identity AND content version of every value: an in-place edit of a condition tensor between steps / chunks (crossattn_emb.copy_,
+            # a refilled pose buffer) must rebuild the concatenated copies, exactly as the DiT's own K / V cache does
+            def _ident(v):
+                return (id(v), v.data_ptr(), tensor_version(v)) if isinstance(v, torch.Tensor) else (id(v),)
+            key = (B,) + tuple(_ident(v) for v in condition.to_dict().values()) + tuple(_ident(v) for v in uncondition.to_dict().values())
             fc = self._fused_cache
             if fc is None or fc[0] != key:
                 # (the cache entry keeps the condition objects alive, so the ids in the key cannot be recycled while it is valid)

@@ -332,6 +332,16 @@ class VideoTokenizer:
         return None  # weights are bf16 by construction
 
     # -- interface
+    # The reference's joint tokenizer exposes its video half as `.video_vae` and helpers outside the class reach through it
+    # (`model.tokenizer.video_vae.pixel_chunk_duration / latent_chunk_duration / is_casual`: inference_utils.py:677-691, 768-782;
+    # JointImageVideoTokenizer, pretrained_vae.py:500-611). This class IS the video tokenizer, so the attribute is an alias of itself; the
+    # image half (`image_vae`) is never reached from GEN3C's entry points and is not provided.
+    is_casual = True  # (sic - the reference's spelling, pretrained_vae.py; "causal")
+
+    @property
+    def video_vae(self) -> "VideoTokenizer":
+        return self
+
     @property
     def channel(self) -> int:
         return self.latent_ch

@@ -11,7 +11,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on that stream;
  *   - tensors are bf16 (uint16 storage) unless the name says f32; leading dims / strides are in ELEMENTS;
  *   - return value: 0 = G3_OK, non-zero = error (g3_last_error() returns a thread-local message);
- *   - thread-compatible: no mutable global state besides lazily-set kernel attributes.
+ *   - thread-compatible: no mutable global state besides lazily-set kernel attributes and the g3_set_option A/B switches (process-wide,
+ *     meant for tools; per-call choices go through the *_ex entry points).
  */
 #ifndef GEN3C_HIP_H
 #define GEN3C_HIP_H
@@ -56,6 +57,9 @@ int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_t ldw, void
                     int epilogue, const void* gate, int gate_rows, int64_t ldg, const void* residual, int64_t ldr,
                     void* stream);
 
+/* Name of the kernel the call above launches for this shape under the options in force (aligned operands assumed): profilers / bench.py only. */
+const char* g3_gemm_kernel_name(int M, int N, int K, int epilogue);
+
 /* out[M<=8][N] = (act_in(a) . w^T) (+ add): TimestepEmbedding (blocks.py:60-80) and adaLN_modulation
  * (blocks.py:411-415, 442-447; FinalLayer blocks.py:212-216, 230). act_in: 0 none, 1 SiLU. */
 int g3_gemv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* add, int64_t ldadd, void* out,
@@ -83,6 +87,25 @@ int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_t q_batch, 
                                  int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head,
                                  int vt_seg_len, int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq,
                                  int Skv, int B, int H, int head_dim, float softmax_scale, void* stream);
+
+/* Extended form of the two calls above (one entry point: vt_seg_len == 0 = plain V^T) for hosts that shard the KEYS of a row over several
+ * launches - the context-parallel schedule that starts on the local K / V shard before any remote shard has arrived, which is what
+ * TransformerEngine's ring does behind attn_op.set_context_parallel_group (general_dit.py:536-541, module/attention.py:228-238):
+ *   variant   per-call kernel choice, 0 = the process-wide "attn_variant" option (whose 0 = automatic). Nothing global is touched, so
+ *             concurrent launches on several streams can use different kernels (4 = 8-wave kernel, 11 = one-wave-per-SIMD kernel).
+ *   o         bf16 result as above, or NULL when o_partial / lse are given:
+ *   o_partial fp32 [Sq][B][H][128] addressed with the SAME element strides o_row / o_batch / o_head: the softmax-NORMALISED result over
+ *             this launch's keys only;  lse fp32 [B][H][Sq] contiguous: log2(sum_k exp2(s_qk * scale * log2 e)) of those keys.
+ * g3_attn_merge_partials_bf16 combines n_parts (1..8) such parts of the same rows into the bf16 result over the union of their keys:
+ *   out = sum_i w_i * o_part_i,  w_i = 2^(lse_i - max lse) / sum_j 2^(lse_j - max lse).  o_parts / lse_parts are HOST arrays of device pointers. */
+int g3_flash_attn_fwd_ex_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
+                              int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
+                              int64_t vt_seg_stride, void* o, float* o_partial, float* lse, int64_t o_row, int64_t o_batch, int64_t o_head,
+                              int Sq, int Skv, int B, int H, int head_dim, float softmax_scale, int variant, void* stream);
+const char* g3_flash_attn_kernel_name_ex(int Sq, int Skv, int B, int H, int variant);
+int g3_attn_merge_partials_bf16(const float* const* o_parts /*host*/, const float* const* lse_parts /*host*/, int n_parts, int64_t p_row,
+                                int64_t p_batch, int64_t p_head, void* out, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int B,
+                                int H, int head_dim, void* stream);
 
 /* V [S][B][H][128] (row stride ld_in) -> V^T [B][H][128][ldvt], zero-filling kv in [S, ldvt). */
 int g3_transpose_v_bf16(const void* v, int64_t ld_in, void* vt, int64_t ldvt, int S, int B, int H, int head_dim,
@@ -171,8 +194,8 @@ int g3_warp_splat_f32(const float* image, const float* z, const float* flow, con
                       float* accum, int n, int h, int w, int group_size, void* stream);
 int g3_warp_resolve_f32(const float* accum, float* frame, float* mask, float* depth, int n, int h, int w, void* stream);
 
-/* g3_warp_splat_f32 + g3_warp_resolve_f32 in one call without global atomics on the common path: every 32x32 source tile stores its 48x48
- * destination window into `workspace` and a destination-owning pass sums the overlapping windows in a fixed order and resolves the pixel
+/* g3_warp_splat_f32 + g3_warp_resolve_f32 in one call without global atomics on the common path: every 32x32 source tile stores its 40x40
+ * destination window (32 KiB; size the workspace with g3_warp_windows_workspace_bytes, never from this text) into `workspace` and a destination-owning pass sums the overlapping windows in a fixed order and resolves the pixel
  * (bilinear_splatting + the normalisation / clamp of forward_warp, forward_warp_utils_pytorch.py:576-695,300-334). Same contributions as
  * the two-call form (whose accumulator still receives the rare out-of-window corners here: zero it first). workspace: g3_warp_windows_workspace_bytes(n, h, w) bytes, 16-byte aligned. depth may be NULL. */
 size_t g3_warp_windows_workspace_bytes(int n, int h, int w);

@@ -108,3 +108,43 @@ def test_single_image_without_moge_asks_for_depth():
         pytest.skip("moge is importable here")
     with pytest.raises(SystemExit, match="depth_path"):
         g._depth_inputs(None, "x.png", None, 704, 1280, "cpu", None)
+
+
+def test_tokenizer_plugin_seam_video_vae_alias():
+    """SURVEY 8b "Tokenizer plugin": helpers outside the class reach the video tokenizer through `model.tokenizer.video_vae.*`
+    (inference_utils.py:677-691 compute_num_latent_frames, :768-782 compute_num_frames_condition). Replay those accesses on
+    gen3c_amd.tokenizer.VideoTokenizer, and - when the reference tree is present - call the reference's own functions on it."""
+    import types
+    from gen3c_amd.tokenizer import VideoTokenizer
+    tk = VideoTokenizer(pixel_chunk_duration=121, channels=16, device="cpu")
+    model = types.SimpleNamespace(tokenizer=tk)
+    v = model.tokenizer.video_vae
+    assert v.pixel_chunk_duration == 121 and v.latent_chunk_duration == 16 and getattr(v, "is_casual", None) is True
+    for name in ("load_weights", "encode", "decode", "reset_dtype", "get_latent_num_frames", "get_pixel_num_frames"):
+        assert callable(getattr(tk, name)), name
+    assert (tk.channel, tk.spatial_compression_factor, tk.temporal_compression_factor) == (16, 8, 8)
+
+    def compute_num_latent_frames(model, num_input_frames, downsample_factor=8):  # the reference's attribute accesses, inference_utils.py:677-691
+        n = num_input_frames // model.tokenizer.video_vae.pixel_chunk_duration * model.tokenizer.video_vae.latent_chunk_duration
+        if num_input_frames % model.tokenizer.video_vae.latent_chunk_duration == 1:
+            n += 1
+        elif num_input_frames % model.tokenizer.video_vae.latent_chunk_duration > 1:
+            assert (num_input_frames % model.tokenizer.video_vae.pixel_chunk_duration - 1) % downsample_factor == 0
+            n += 1 + (num_input_frames % model.tokenizer.video_vae.pixel_chunk_duration - 1) // downsample_factor
+        return n
+
+    from gen3c_amd import pipeline
+    for n_in in (1, 9, 17, 122):
+        assert compute_num_latent_frames(model, n_in) == pipeline.compute_num_latent_frames(model, n_in)
+    ref_file = Path("/root/reference/cosmos_predict1/diffusion/inference/inference_utils.py")
+    if ref_file.is_file():  # build container only: the reference's own function BODIES (cut out with ast - the module's import chain needs
+        import ast          # omegaconf / imageio / megatron, none of which these two functions use), executed on our tokenizer
+        src = ref_file.read_text()
+        ns = {}
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.FunctionDef) and node.name in ("compute_num_latent_frames", "compute_num_frames_condition"):
+                exec(compile("from __future__ import annotations\n" + ast.get_source_segment(src, node), str(ref_file), "exec"), ns)
+        assert len([k for k in ns if k.startswith("compute_")]) == 2
+        for n_in in (1, 9, 17, 122):
+            assert ns["compute_num_latent_frames"](model, n_in) == pipeline.compute_num_latent_frames(model, n_in)
+        assert [ns["compute_num_frames_condition"](model, k) for k in (1, 2, 16)] == [1, 9, 121]

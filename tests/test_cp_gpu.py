@@ -65,13 +65,47 @@ def test_cp_attention_two_stream_one_wave_kernel_single_rank():
         # gloo moves the (CPU-staged) tensors of the 1-rank all-gather; the kernels and streams are the product ones
         cpa = ContextParallelAttention(group, head_groups=4)
         out = cpa(q, k, v, S, B, H)
-        ops.set_option("attn_variant", 11)
-        try:
-            ref = ops.flash_attn(q, k, ops.transpose_v(v, S, B, H), S, S, B, H)
-        finally:
-            ops.set_option("attn_variant", 0)
+        ref = ops.flash_attn(q, k, ops.transpose_v(v, S, B, H), S, S, B, H, variant=11)
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+        # the kernel choice is per call: explicit "wave8" gives the 8-wave kernel's bits, and the library's process-wide option is untouched
+        from gen3c_amd import _lib
+        name0 = _lib.load().g3_flash_attn_kernel_name(S, S, B, H)
+        out8 = ContextParallelAttention(group, head_groups=4, kernel="wave8")(q, k, v, S, B, H)
+        assert torch.equal(out8, ops.flash_attn(q, k, ops.transpose_v(v, S, B, H), S, S, B, H, variant=4))
+        assert _lib.load().g3_flash_attn_kernel_name(S, S, B, H) == name0
+        # local-first schedule with one rank: the local part is everything, merged alone (fp32 partial -> bf16)
+        cpl = ContextParallelAttention(group, head_groups=4, schedule="local_first")
+        cpl.stats = []
+        outl = cpl(q, k, v, S, B, H)
+        torch.cuda.synchronize()
+        assert float((outl.float() - ref.float()).norm() / ref.float().norm()) < 1e-3
+        assert len(cpl.stats) == 4 and all(kind == "wait" and tm.elapsed_ms() >= 0 for kind, _g, tm in cpl.stats)
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_path_autotunes_and_prints_cp_object():
+    """`python bench.py --gpus 2` through its own launcher with both ranks on cuda:0 over gloo (plumbing run of the driver's N > 1 command,
+    reduced size): the context-parallel autotune runs, the timed region runs on the winner, and the JSON line carries the `cp` diagnosis."""
+    import json
+    import os
+    env = dict(os.environ, G3_BENCH_BACKEND="gloo", G3_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--blocks", "4", "--latent", "8,16,24",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["output_finite"] and out["scaling"] == "strong"
+    cp = out["cp"]
+    assert cp["chosen"]["head_groups"] in (1, 2, 4, 8) and cp["chosen"]["kernel"] in ("w4b", "wave8") and cp["chosen"]["schedule"] in ("gather_first", "local_first")
+    assert len(cp["autotune_ms"]) == 16 and min(r_["ms"] for r_ in cp["autotune_ms"]) == cp["chosen"]["ms"]
+    for key in ("attention_ms_per_step", "gemm_ms_per_step", "exposed_collective_wait_ms_per_step", "gathered_bytes_per_step", "rccl_ranks"):
+        assert key in cp, key
+    # 4 blocks x (K + V shard of the other rank): 2 forwards batched as B = 2 -> rows = 384 * 2, 4096 features, bf16
+    assert cp["gathered_bytes_per_step"] == 4 * 2 * (384 * 2 * 4096 * 2)
+    print(json.dumps(cp)[:1500])

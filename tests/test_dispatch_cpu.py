@@ -47,3 +47,21 @@ def test_fused_cond_uncond_arguments():
     # conditions that cannot share one call: different flags / shapes -> None (the sampler then makes two calls)
     assert Gen3CDenoiser._fused_cond_uncond_kwargs(c, _cond(torch.randn(1, 5, 8), torch.zeros(1, 3, 2, 2, 2), flag=False), 1) is None
     assert Gen3CDenoiser._fused_cond_uncond_kwargs(c, _cond(torch.randn(1, 6, 8), torch.zeros(1, 3, 2, 2, 2)), 1) is None
+
+
+def test_cache_keys_work_on_inference_tensors():
+    """the reference wraps its pipeline entry points in torch.inference_mode() (world_generation_pipeline.py:1225); inference
+    tensors raise on `_version`. The cache keys must not."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT, tensor_version
+    with torch.inference_mode():
+        t = torch.zeros(3)
+    assert t.is_inference() and tensor_version(t) == -1
+    u = torch.zeros(3)
+    v0 = tensor_version(u)
+    u.add_(1)
+    assert tensor_version(u) == v0 + 1
+    with torch.inference_mode():
+        net = VideoExtendGeneralDIT(max_img_h=16, max_img_w=16, max_frames=8, in_channels=81, model_channels=128, num_blocks=1, num_heads=1,
+                                    adaln_lora_dim=8, crossattn_emb_channels=16, device="cpu", init_weights=True)
+        k1 = net._weights_key()  # parameters created under inference mode
+    assert k1 == net._weights_key()

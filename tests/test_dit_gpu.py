@@ -42,8 +42,9 @@ def test_dit_forward_matches_reference_golden(name):
     mx = float((y - y_ref).abs().max())
     print(f"[{name}] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
     assert torch.isfinite(y).all()
-    assert rel <= 2e-2
-    assert mx <= 6e-2 * float(y_ref.abs().max())
+    # measured 5.4e-3 / 2.8e-2 (profiles/r2_parity_measured.txt); bound = measured + margin, so a 2x regression fails
+    assert rel <= 9e-3
+    assert mx <= 4.5e-2 * float(y_ref.abs().max())
 
 
 def test_dit_forward_long_sequence_vs_oracle():
@@ -77,7 +78,7 @@ def test_dit_forward_long_sequence_vs_oracle():
     mx = float((y - y_ref).abs().max())
     print(f"[dit 2304 tokens] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
     assert y.shape == y_ref.shape and torch.isfinite(y).all()
-    assert rel <= 2e-2 and mx <= 6e-2 * float(y_ref.abs().max())
+    assert rel <= 9e-3 and mx <= 4.5e-2 * float(y_ref.abs().max())  # measured + margin (see the golden test above)
 
 
 def test_dit_full_width_block_vs_oracle():
@@ -145,3 +146,31 @@ def test_cross_attention_kv_cache_follows_context_and_weights():
     y3 = net(crossattn_emb=ctx2, **kw)
     assert not torch.equal(y3, y2)
     assert len(net._ca_kv_cache) <= 4
+
+
+def test_dit_forward_under_inference_mode_matches_no_grad():
+    """forward() must run when the caller wraps it in torch.inference_mode() (the reference's pipelines do) - weights created
+    under it, context tensor created under it - and give the bits of the no_grad call."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    dev = torch.device("cuda:0")
+
+    def run(ctx_mgr):
+        with ctx_mgr():
+            net = VideoExtendGeneralDIT(max_img_h=48, max_img_w=48, max_frames=16, in_channels=81, model_channels=256, num_blocks=1, num_heads=2,
+                                        adaln_lora_dim=32, crossattn_emb_channels=128, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+            net.initialize_weights(randomize_adaln=True, seed=5)
+            g = torch.Generator().manual_seed(9)
+            B, T, H, W, M = 1, 2, 16, 16, 16
+            x = torch.randn(B, 16, T, H, W, generator=g).to(torch.bfloat16).to(dev)
+            mask = torch.zeros(B, 1, T, H, W, dtype=torch.bfloat16, device=dev)
+            pose = torch.randn(B, 64, T, H, W, generator=g).to(torch.bfloat16).to(dev)
+            ctx = torch.randn(B, M, 128, generator=g).to(torch.bfloat16).to(dev)
+            kw = dict(timesteps=torch.tensor([0.3], dtype=torch.bfloat16, device=dev), crossattn_emb=ctx, crossattn_mask=None,
+                      fps=torch.tensor([24.0], device=dev), padding_mask=torch.zeros(B, 1, 8 * H, 8 * W, dtype=torch.bfloat16, device=dev),
+                      condition_video_indicator=mask[:, :, :, :1, :1], condition_video_input_mask=mask, condition_video_pose=pose)
+            y1 = net(x=x, **kw)
+            y2 = net(x=x, **kw)  # second call: cached cross-attention K / V, cached tables
+            assert torch.equal(y1, y2)
+            return y1.float().cpu()
+
+    assert torch.equal(run(torch.inference_mode), run(torch.no_grad))

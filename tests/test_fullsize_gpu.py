@@ -69,3 +69,87 @@ def test_gemm_full_size_sampled_rows_and_row_subsets(N, K, epi):
     kw2 = dict(gate=gate, residual=res[sub].contiguous()) if epi == 2 else {}
     out_sub = ops.gemm_nt(a[sub].contiguous(), w, epilogue=epi, **kw2)
     assert torch.equal(out_sub, out[sub])
+
+
+def _bench_launch_operands(dev, H=32, B=2, seed=11):
+    """The operands of the benchmark's self-attention launch, produced the way the DiT forward produces them: ONE fused QKV projection
+    (g3_gemm_qk_norm_rope_bf16) writes q | k (per-head RMSNorm + RoPE in the epilogue) into a [S*B, 3*H*128] buffer and the v heads
+    straight into V^T. q / k handed to the attention kernel are strided column views of that buffer (k offsets reach 2.77 GB of the
+    kernel's 32-bit byte-offset budget at H = 32, B = 2)."""
+    from gen3c_amd import ops
+    g = torch.Generator(device=dev).manual_seed(seed)
+    Dm = H * HD
+    h = torch.randn(S * B, Dm, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3 * Dm, Dm, device=dev, generator=g) / math.sqrt(Dm)).to(torch.bfloat16)
+    nq = (1.0 + 0.1 * torch.randn(HD, device=dev, generator=g)).to(torch.bfloat16)
+    nk = (1.0 + 0.1 * torch.randn(HD, device=dev, generator=g)).to(torch.bfloat16)
+    ang = torch.rand(S, HD // 2, device=dev, generator=g) * 6.2831853
+    ang = torch.cat([ang, ang], dim=-1)
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    vt = torch.zeros(B, H, HD, ops.ceil_to(S, 64), device=dev, dtype=torch.bfloat16)
+    qkv = ops.gemm_qk_norm_rope(h, w, Dm, Dm, nq, nk, cos, sin, S, B, vt=vt)
+    return dict(h=h, w=w, nq=nq, nk=nk, ang=ang, qkv=qkv, vt=vt, Dm=Dm)
+
+
+def test_bench_attention_launch_w4b_xcd_grid_vs_fp32():
+    """the launch bench.py times - flash_attn_fwd_w4b_kernel<true>, 1-D XCD-local grid, S = 56 320, H = 32, B = 2,
+    q / k as column views of the fused QKV buffer, V^T written by the QKV epilogue - against an fp32 softmax on sampled rows.
+    (batch, head) pair hb = b*H + h is worked on by XCD hb % 8 (attention_w4b.hpp): the 8 checked pairs cover all 8 XCDs, both batch
+    items, the first and the last head. 256 sampled rows per pair: the first / last row block (prologue and ragged tail paths) + random ones."""
+    from gen3c_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    H, B = 32, 2
+    name = _lib.load().g3_flash_attn_kernel_name(S, S, B, H).decode()
+    assert name == "flash_attn_fwd_w4b_kernel<true>", f"the automatic choice for the benchmark shape is {name}"
+    op = _bench_launch_operands(dev, H, B)
+    Dm, qkv, vt = op["Dm"], op["qkv"], op["vt"]
+    q, k = qkv[:, :Dm], qkv[:, Dm:2 * Dm]
+    assert q.stride(0) == 3 * Dm and k.data_ptr() - qkv.data_ptr() == 2 * Dm  # strided views, nothing repacked
+    ops.enable_kernel_timers(True)
+    out = ops.flash_attn(q, k, vt, S, S, B, H)
+    launched = [m for (n, m, _t) in ops.collected_kernel_timers() if n == "flash_attn_fwd"]
+    ops.enable_kernel_timers(False)
+    assert launched and launched[-1]["kernel"] == "flash_attn_fwd_w4b_kernel<true>", launched
+    assert torch.isfinite(out.float()).all()
+    g = torch.Generator(device=dev).manual_seed(3)
+    rows = torch.cat([torch.arange(0, 64, device=dev), torch.randint(64, S - 64, (128,), device=dev, generator=g), torch.arange(S - 64, S, device=dev)])
+    worst = 0.0
+    for (b, hh) in [(0, 0), (0, 9), (0, 18), (0, 27), (1, 4), (1, 13), (1, 22), (1, 31)]:
+        assert (b * H + hh) % 8 == [(0, 0), (0, 9), (0, 18), (0, 27), (1, 4), (1, 13), (1, 22), (1, 31)].index((b, hh))
+        sl = slice(hh * HD, (hh + 1) * HD)
+        qs = q[rows * B + b][:, sl].float()
+        ks = k[b::B][:, sl].float()
+        vs = vt[b, hh, :, :S].float().t()
+        ref = torch.softmax((qs @ ks.t()) / math.sqrt(HD), dim=-1) @ vs
+        r = _rel_l2(out[rows * B + b][:, sl], ref)
+        worst = max(worst, r)
+        assert r < 4e-3, f"(b={b}, h={hh}): rel-L2 {r:.3e} vs fp32 softmax on 256 sampled rows"
+    print(f"[bench attention launch w4b<true> S=56320 H=32 B=2] worst rel-L2 over 8 (batch, head) pairs = {worst:.3e}")
+
+
+def test_bench_qkv_epilogue_vs_fp32_norm_rope():
+    """The fused QKV epilogue at the benchmark size (S = 56 320, B = 2, D = 4096) against an fp32 evaluation of Attention.cal_qkv
+    (attention.py:247-280: Linear, per-head RMSNorm with weight, non-interleaved RoPE; v plain) on sampled rows - not against the unfused kernels."""
+    from oracle import dit_oracle
+    dev = torch.device("cuda:0")
+    H, B = 32, 2
+    op = _bench_launch_operands(dev, H, B, seed=12)
+    Dm, qkv, vt = op["Dm"], op["qkv"], op["vt"]
+    g = torch.Generator(device=dev).manual_seed(5)
+    srow = torch.cat([torch.arange(0, 16, device=dev), torch.randint(16, S - 16, (96,), device=dev, generator=g), torch.arange(S - 16, S, device=dev)])  # tokens
+    for b in range(B):
+        rows = srow * B + b
+        y = op["h"][rows].float() @ op["w"].float().t()  # [n, 3 Dm] fp32
+        fr = op["ang"][srow].reshape(-1, 1, 1, HD)
+        for name, c0, nw in (("q", 0, op["nq"]), ("k", Dm, op["nk"])):
+            t = y[:, c0:c0 + Dm].reshape(-1, 1, H, HD)
+            ref = dit_oracle.te_rope_fused(dit_oracle.te_rmsnorm(t, nw.float()), fr).reshape(-1, Dm)
+            r = _rel_l2(qkv[rows][:, c0:c0 + Dm], ref)
+            # three bf16 roundings on the kernel's path (projection, norm, rope - TE's rounding points) vs none in the reference
+            assert r < 6e-3, f"{name} (b={b}): rel-L2 {r:.3e} vs fp32 RMSNorm + RoPE"
+        vref = y[:, 2 * Dm:].reshape(-1, H, HD)
+        vgot = vt[b][:, :, srow].permute(2, 0, 1)
+        r = _rel_l2(vgot, vref)
+        assert r < 4e-3, f"v^T (b={b}): rel-L2 {r:.3e}"
+    if vt.shape[-1] > S:
+        assert float(vt[:, :, :, S:].float().abs().max()) == 0.0  # the zero tail the attention kernel relies on

@@ -485,3 +485,104 @@ def test_gemm_known_answer_constant_weights():
         expect = K * float(torch.tensor(0.1, dtype=torch.bfloat16))  # 0.1 is rounded to bf16 once, then summed exactly in fp32
         torch.testing.assert_close(out, torch.full_like(out, expect), rtol=1e-2, atol=0)  # rtol of the reference test
         assert float(out.std()) == 0.0
+
+
+@pytest.mark.parametrize("variant", [4, 11])
+@pytest.mark.parametrize("S_local,world,rank,B,H", [(3520, 4, 1, 1, 8), (1024, 8, 0, 2, 4), (704, 2, 1, 1, 2)])
+def test_flash_attn_split_kv_partials_merge(variant, S_local, world, rank, B, H):
+    """Split-KV attention: the keys of a row are covered by several launches that return a normalised fp32 partial +
+    log-sum-exp each (g3_flash_attn_fwd_ex_bf16), merged by g3_attn_merge_partials_bf16. Layout as under context parallelism: K gathered
+    rank-major, V^T in per-rank key segments; parts = this rank's own shard, the ranks before it, the ranks after it. Must match the
+    single call over all keys (<= 3e-3: one extra rounding pattern, fp32 partials) and an fp32 softmax (<= 1e-2, the attention tolerance)."""
+    from gen3c_amd import ops
+    dev = _dev()
+    S_all = S_local * world
+    g = torch.Generator(device=dev).manual_seed(S_local + world + rank)
+    q = torch.randn(S_local * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(S_all * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(S_all * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    rows = S_local * B
+    vt_seg = torch.stack([ops.transpose_v(v[r * rows:(r + 1) * rows], S_local, B, H) for r in range(world)])  # [world, B, H, 128, S_local]
+    full = ops.flash_attn(q, k, vt_seg, S_local, S_all, B, H, variant=variant)
+    parts = []
+    for (r0, r1) in ((rank, rank + 1), (0, rank), (rank + 1, world)):
+        if r1 > r0:
+            parts.append(ops.flash_attn(q, k[r0 * rows:r1 * rows], vt_seg[r0:r1].contiguous(), S_local, (r1 - r0) * S_local, B, H, variant=variant, partial=True))
+    merged = ops.attn_merge(parts, S_local, B, H)
+    r_split = _rel_l2(merged, full)
+    worst = 0.0
+    for b in range(B):
+        for h in range(H):
+            sl = slice(h * 128, (h + 1) * 128)
+            sc = (q[b::B, sl].float() @ k[b::B, sl].float().t()) / math.sqrt(128)
+            ref = torch.softmax(sc, dim=-1) @ v[b::B, sl].float()
+            worst = max(worst, _rel_l2(merged[b::B, sl], ref))
+    print(f"[split-kv v{variant} S_local={S_local} world={world} rank={rank} B={B} H={H}] {len(parts)} parts: vs one call {r_split:.3e}, vs fp32 {worst:.3e}")
+    assert r_split <= 3e-3 and worst <= 1e-2
+    # a single part merged alone is the plain result (weights = 1): fp32 partial -> bf16 once
+    one = ops.attn_merge([ops.flash_attn(q, k, vt_seg, S_local, S_all, B, H, variant=variant, partial=True)], S_local, B, H)
+    assert _rel_l2(one, full) <= 1e-6 or torch.equal(one, full)
+
+
+def test_flash_attn_per_call_variant_leaves_global_option_alone():
+    """the context-parallel path used to toggle the process-global "attn_variant" around launches; the choice is now an argument."""
+    from gen3c_amd import _lib, ops
+    dev = _dev()
+    lib = _lib.load()
+    S, H = 4096, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    q, k, v = (torch.randn(S, H * 128, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+    vt = ops.transpose_v(v, S, 1, H)
+    auto_name = lib.g3_flash_attn_kernel_name(S, S, 1, H)
+    a = ops.flash_attn(q, k, vt, S, S, 1, H, variant=4)
+    b = ops.flash_attn(q, k, vt, S, S, 1, H, variant=11)
+    assert lib.g3_flash_attn_kernel_name(S, S, 1, H) == auto_name
+    assert lib.g3_flash_attn_kernel_name_ex(S, S, 1, H, 4).decode().startswith("flash_attn_fwd_v3_kernel")
+    assert lib.g3_flash_attn_kernel_name_ex(S, S, 1, H, 11).decode() == "flash_attn_fwd_w4b_kernel<true>"
+    assert _rel_l2(a, b) < 6e-3
+
+
+def test_hip_dot_product_attention_operator_seam():
+    """SURVEY 8b "Attention operator": the reference's Attention module calls attn_op(q, k, v, core_attention_bias_type="no_bias",
+    core_attention_bias=None) on sbhd tensors and expects [S, B, H*d] (attention.py:282-297); general_dit.py:541 hands the operator a
+    context-parallel group. gen3c_amd.attention_op.HipDotProductAttention on [S, B, 32, 128] inputs vs an fp32 softmax."""
+    import os
+    import torch.distributed as dist
+    from gen3c_amd.attention_op import HipDotProductAttention
+    dev = _dev()
+    S, B, H = 1536, 2, 32
+    g = torch.Generator(device=dev).manual_seed(77)
+    q, k, v = (torch.randn(S, B, H, 128, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+    op = HipDotProductAttention(H, 128, num_gqa_groups=H, attention_dropout=0, qkv_format="sbhd", attn_mask_type="no_mask", tp_size=1,
+                                tp_group=None, sequence_parallel=False)  # the reference's constructor call, attention.py:228-238
+    out = op(q, k, v, core_attention_bias_type="no_bias", core_attention_bias=None)
+    assert out.shape == (S, B, H * 128) and out.dtype == torch.bfloat16
+    qf, kf, vf = (t.permute(1, 2, 0, 3).float() for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(128), dim=-1) @ vf).permute(2, 0, 1, 3).reshape(S, B, H * 128)
+    r = _rel_l2(out, ref)
+    print(f"[HipDotProductAttention sbhd S={S} B={B} H={H}] rel-L2 vs fp32 {r:.3e}")
+    assert r < 4e-3
+    with pytest.raises(NotImplementedError):
+        op(q, k, v, core_attention_bias_type="post_scale_bias", core_attention_bias=torch.zeros(1, device=dev))
+    # the context-parallel hook with a 1-rank group (gloo): every collective call of the CP path runs, result = the plain call
+    created = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        grp = dist.new_group([0])
+        op.set_context_parallel_group(grp, [0], torch.cuda.Stream())
+        out_cp = op(q, k, v, core_attention_bias_type="no_bias", core_attention_bias=None)
+        torch.cuda.synchronize()
+        assert _rel_l2(out_cp, out) < 3e-3  # (kernel choice per head group may differ from the single launch's)
+        op.set_context_parallel_group(None, None, None)
+        assert torch.equal(op(q, k, v), out)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -2,6 +2,7 @@
 head-group schedule of ContextParallelAttention - checked against the single-process oracle attention.
 The HIP kernels themselves cannot run here, so the attention/transpose callables are the oracle's (this is the one
 place a `backend` is injected; the product path never does)."""
+import math
 import os
 import socket
 
@@ -25,7 +26,7 @@ def _oracle_backend():
     def transpose_v(v, S, B, H):
         return v.reshape(S, B, H, 128).permute(1, 2, 3, 0).contiguous()  # [B,H,128,S]
 
-    def attention(q, k, vt, Sq, Skv, B, H, out):
+    def attention(q, k, vt, Sq, Skv, B, H, out, variant=0):
         q4 = q.reshape(Sq, B, H, 128)
         k4 = k.reshape(Skv, B, H, 128)
         if vt.dim() == 5:  # rank-major V^T segments [n, B, H, 128, S_local] (context-parallel gather of local transposes)
@@ -36,7 +37,27 @@ def _oracle_backend():
         out.copy_(dit_oracle.attention_sbhd(q4, k4, v4).reshape(Sq * B, H * 128))
         return out
 
-    return dict(pack=lambda t: t.contiguous(), transpose_v=transpose_v, attention=attention)
+    def attention_partial(q, k, vt, Sq, Skv, B, H, variant=0):
+        # normalised partial result + log2-domain log-sum-exp, like g3_flash_attn_fwd_ex_bf16 (fp64 reference arithmetic)
+        q4 = q.reshape(Sq, B, H, 128).permute(1, 2, 0, 3).double()
+        k4 = k.reshape(Skv, B, H, 128).permute(1, 2, 0, 3).double()
+        n, S_loc = vt.shape[0], vt.shape[-1]
+        v4 = vt.permute(0, 4, 1, 2, 3).reshape(n * S_loc, B, H, 128).permute(1, 2, 0, 3).double()
+        sc = q4 @ k4.transpose(-1, -2) / math.sqrt(128.0)
+        lse = torch.logsumexp(sc, dim=-1)  # [B,H,Sq] natural log
+        o = torch.softmax(sc, dim=-1) @ v4  # [B,H,Sq,128]
+        return o.permute(2, 0, 1, 3).reshape(Sq * B, H * 128).float(), (lse / math.log(2.0)).float().contiguous()
+
+    def merge(parts, Sq, B, H, out):
+        l = torch.stack([p[1].double() for p in parts])  # [n,B,H,Sq]
+        w = torch.softmax(l * math.log(2.0), dim=0)
+        acc = 0
+        for i, (o, _) in enumerate(parts):
+            acc = acc + o.double().reshape(Sq, B, H, 128) * w[i].permute(2, 0, 1)[..., None]
+        out.copy_(acc.reshape(Sq * B, H * 128).to(out.dtype))
+        return out
+
+    return dict(pack=lambda t: t.contiguous(), transpose_v=transpose_v, attention=attention, attention_partial=attention_partial, merge=merge)
 
 
 def _worker(rank, world, port, tmp):
@@ -75,6 +96,13 @@ def _worker(rank, world, port, tmp):
             assert pending["segmented"] == (Sl % 64 == 0)
             out = cpa.finish(qkv_local[:, :D], pending)
             torch.testing.assert_close(out, ref[rows], rtol=1e-5, atol=1e-5)
+            # local-KV-first schedule: own shard first (no wait), remote segments after the exchange, merged (falls back to gather-first when
+            # V cannot be gathered as key segments, S_local % 64 != 0)
+            cpl = parallel.ContextParallelAttention(group, head_groups=2, backend=_oracle_backend(), schedule="local_first")
+            b0 = cpl.bytes_gathered
+            out2 = cpl(qkv_local[:, :D], qkv_local[:, D:2 * D], qkv_local[:, 2 * D:], Sl, B, H)
+            torch.testing.assert_close(out2, ref[rows], rtol=1e-5, atol=1e-5)
+            assert cpl.bytes_gathered - b0 == (world - 1) * 2 * Sl * B * D * 4  # fp32 K + V shards of the other ranks
         with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:

@@ -70,8 +70,15 @@ def _chain(n_buffers: int, guidance: float, num_steps: int):
     model.scheduler.set_timesteps(num_steps)
     xt = (torch.randn(1, 16, 2, H // 8, W // 8, generator=g) * model.scheduler.init_noise_sigma).to(torch.bfloat16)
     image = t(img)[None, :, None]  # [1,3,1,H,W]
-    video = pipe.generate(prompt, image, renders, masks, negative_prompt_embedding=negp, xt=xt.to(dev))
+    video = pipe.generate_from_embeddings(prompt, image, renders, masks, negative_prompt_embedding=negp, xt=xt.to(dev))
     assert video.shape == (T, H, W, 3) and video.dtype == np.uint8
+    if num_steps == 3 and n_buffers == 1:
+        # the reference's seam, called with the keywords gen3c_single_image.py:366-372 uses (tensor image as in its autoregressive loop :411-417;
+        # strings go through the text encoder handed to the pipeline): same bits, returns (video, prompt)
+        pipe.text_encoder = lambda text: {"a prompt": prompt, "a negative prompt": negp}[text]
+        out2 = pipe.generate(prompt="a prompt", image_path=image, negative_prompt="a negative prompt", rendered_warp_images=renders,
+                             rendered_warp_masks=masks, xt=xt.to(dev))
+        assert isinstance(out2, tuple) and out2[1] == "a prompt" and np.array_equal(out2[0], video)
 
     # ---- the same chain from the CPU oracles (fp32)
     src = []
@@ -126,21 +133,24 @@ def _chain(n_buffers: int, guidance: float, num_steps: int):
     ref_video = ((1.0 + y).clamp(0, 2) / 2)[0].permute(1, 2, 3, 0).numpy()
 
     got = video.astype(np.float32) / 255.0
-    mse = float(((got - ref_video) ** 2).mean())
-    return 10 * np.log10(1.0 / max(mse, 1e-12)), mse
+    # per-frame PSNR (north_star: "per-frame PSNR"): the bound is on the WORST frame, a bad first / last frame cannot hide in a clip mean
+    mse_f = ((got - ref_video) ** 2).reshape(got.shape[0], -1).mean(axis=1)
+    psnr_f = 10 * np.log10(1.0 / np.maximum(mse_f, 1e-12))
+    print("[e2e] per-frame PSNR: " + " ".join(f"{p:.1f}" for p in psnr_f))
+    return float(psnr_f.min()), float(mse_f.max())
 
 
 def test_single_image_chunk_end_to_end():
     psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=3)
-    print(f"[e2e] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
-    assert psnr >= 30.0
+    print(f"[e2e] decoded video: minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (worst-frame mse {mse:.2e})")
+    assert psnr >= 33.0  # whole-clip value measured 37.5 dB
 
 
 def test_two_buffers_guidance_end_to_end():
     """N = 2 cache buffers through encode_warped_frames (both (render, mask) latent pairs, no zero padding; reference pairs = both
     buffers of one target frame) and classifier-free guidance 1.5 (c + g (c - u) with a negative prompt and zeroed pose)."""
     psnr, mse = _chain(n_buffers=2, guidance=1.5, num_steps=3)
-    print(f"[e2e N=2 g=1.5] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
+    print(f"[e2e N=2 g=1.5] decoded video minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
     assert psnr >= 33.0  # measured 37.6 dB
 
 
@@ -149,7 +159,7 @@ def test_full_schedule_trajectory_drift():
     the bf16 HIP trajectory must stay within a stated distance of the fp32 oracle trajectory - drift bound: decoded PSNR >= 33 dB
     (measured 37.4 dB, the same as after 3 steps: 37.5 dB - no accumulation over the schedule)."""
     psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=35)
-    print(f"[e2e 35 steps] decoded video PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
+    print(f"[e2e 35 steps] decoded video minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
     assert psnr >= 33.0
 
 

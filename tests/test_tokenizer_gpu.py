@@ -33,7 +33,7 @@ def test_tokenizer_matches_reference_golden():
     ry = _rel(y, y_ref)
     print(f"[tokenizer golden] encoder rel_l2={rz:.3e}  decoder rel_l2={ry:.3e}")
     assert torch.isfinite(z.float()).all() and torch.isfinite(y.float()).all()
-    assert rz <= 3e-2 and ry <= 4e-2
+    assert rz <= 2e-2 and ry <= 1.6e-2  # measured 1.3e-2 / 0.9e-2; bound = measured + margin
 
 
 def test_tokenizer_wide_channels_vs_oracle():
@@ -55,7 +55,7 @@ def test_tokenizer_wide_channels_vs_oracle():
     torch.cuda.synchronize()
     print(f"[tokenizer ch64] encoder rel_l2={rz:.3e}  decoder rel_l2={ry:.3e}  shapes {tuple(z.shape)} {tuple(y.shape)}")
     assert z.shape == z_ref.shape and y.shape == y_ref.shape
-    assert rz <= 3e-2 and ry <= 4e-2
+    assert rz <= 2e-2 and ry <= 1.6e-2  # measured 1.3e-2 / 0.9e-2; bound = measured + margin
 
 
 @pytest.mark.parametrize("T,H,W", [(17, 352, 640), (9, 704, 1280)])
@@ -184,7 +184,7 @@ def test_video_tokenizer_load_weights_from_jit_archives(tmp_path):
     y = tk.decode(((zin.float() - m) / s).to(torch.bfloat16).to(dev))
     ry = _rel(y, y_ref)
     print(f"[tokenizer jit archives] encode rel_l2={rz:.3e} decode rel_l2={ry:.3e}")
-    assert rz <= 3e-2 and ry <= 4e-2
+    assert rz <= 2e-2 and ry <= 1.6e-2  # measured 1.3e-2 / 0.9e-2; bound = measured + margin
 
 
 @pytest.mark.parametrize("rows,n,ld", [(37, 14080, 14080), (16, 1024, 1100 // 8 * 8), (5, 16392, 16392), (9, 100, 104), (3, 16384, 16384)])

@@ -63,3 +63,23 @@ def test_c_bruteforce_ray_triangle_is_bit_identical_to_the_numpy_restatement():
     tr[10:20, :, 2] = 0.0    # in the camera plane
     a, b = warp_oracle.ray_triangle_depth(rays[::3, ::3], tr), warp_oracle.ray_triangle_depth_c(rays[::3, ::3], tr)
     assert (a > 0).mean() > 0.3 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_ray_triangle_restatements_match_the_reference_warp_kernel_source():
+    """tests/golden/warp_kernel_small.npz = the inputs / depth maps of the reference's own `ray_triangle_intersection_warp`
+    (ray_triangle_intersection_warp.py:23-105, 194-292) as called by its forward_warp(foreground_masking=True) on the warp_small scene, the
+    `@wp.kernel` body executed under tools/wp_standin.py (fp32 scalars / vec3, one rounding per operation; tools/gen_golden_warp_kernel.py).
+    The numpy restatement and the C brute force must reproduce the depth maps BIT FOR BIT. (What stays unpinned: the instruction
+    selection of a real Warp / NVRTC build, e.g. fma contraction - warp-lang is not installable here.)"""
+    z = _load("warp_kernel_small")
+    n = int(z["n_calls"])
+    assert n == 2
+    for i in range(n):
+        dirs, verts, faces, depth = z[f"c{i}_dirs"], z[f"c{i}_vertices"], z[f"c{i}_faces"], z[f"c{i}_depth"]
+        assert not z[f"c{i}_origins"].any()  # camera-space rays start at the origin (forward_warp_utils_pytorch.py:705-721): the restatements assume it
+        tris = verts[faces]
+        assert tris.shape[1:] == (3, 3) and len(tris) > 100 and (depth > 0).sum() > 500
+        a = warp_oracle.ray_triangle_depth(dirs, tris)
+        assert np.array_equal(a.view(np.uint32), depth.view(np.uint32)), f"call {i}: numpy restatement differs on {(a != depth).sum()} rays"
+        b = warp_oracle.ray_triangle_depth_c(dirs, tris)
+        assert np.array_equal(b.view(np.uint32), depth.view(np.uint32)), f"call {i}: C restatement differs on {(b != depth).sum()} rays"
