@@ -84,39 +84,64 @@ G3_DEVICE void haar8(const float (&v)[8], float (&o)[8], float scale) {  // inde
     for (int i = 0; i < 8; i += 2) { o[i] = (b[i] + b[i + 1]) * scale; o[i + 1] = (b[i] - b[i + 1]) * scale; }  // w
 }
 
-__global__ __launch_bounds__(256) void haar_patch_kernel(const bf16_t* __restrict__ video, bf16_t* __restrict__ out, int T, int H,
-                                                         int W, int Tp, int Hp, int Wp) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)Tp * Hp * Wp * 3;
-    if (idx >= total) return;
-    const int xo = (int)(idx % Wp);
-    const int yo = (int)((idx / Wp) % Hp);
-    const int to = (int)((idx / ((int64_t)Wp * Hp)) % Tp);
-    const int c = (int)(idx / ((int64_t)Wp * Hp * Tp));
-    const bf16_t* vc = video + (int64_t)c * T * H * W;
-    float l1[8][8];  // [level-1 band][level-1 block (bt,by,bx)]
+// One thread = one output position (t', y', x') and all three colour channels: its 192 coefficients are one contiguous 384-byte row of the
+// channels-last output. Reads: per (colour, frame, line) the thread's 4 pixels are one 8-byte load, neighbouring threads are neighbours in
+// memory (512 contiguous bytes per wave instruction). Writes: the block's 128 rows are one contiguous 48 KiB span - staged through LDS
+// (rows padded to 400 bytes: 16-byte ds accesses of 16 consecutive lanes then cover all 64 banks) and stored 16 bytes per lane, fully coalesced.
+// (The first form - one thread per colour channel, 2-byte loads, 2-byte stores 6 bytes apart - ran at a tenth of the streaming rate.)
+constexpr int HAAR_BLOCK = 128;
+constexpr int HAAR_ROW_BYTES = 400;
+__global__ __launch_bounds__(HAAR_BLOCK) void haar_patch_kernel(const bf16_t* __restrict__ video, bf16_t* __restrict__ out, int T, int H,
+                                                                int W, int Tp, int Hp, int Wp) {
+    __shared__ __attribute__((aligned(16))) char stage[HAAR_BLOCK * HAAR_ROW_BYTES];
+    const int64_t total = (int64_t)Tp * Hp * Wp;
+    const int64_t idx0 = (int64_t)blockIdx.x * HAAR_BLOCK;
+    const int64_t idx = idx0 + threadIdx.x;
+    if (idx < total) {
+        const int xo = (int)(idx % Wp);
+        const int yo = (int)((idx / Wp) % Hp);
+        const int to = (int)(idx / ((int64_t)Wp * Hp));
+        bf16_t* srow = reinterpret_cast<bf16_t*>(stage + threadIdx.x * HAAR_ROW_BYTES);
+        for (int c = 0; c < 3; ++c) {
+            const bf16_t* vc = video + (int64_t)c * T * H * W;
+            float px[4][4][4];  // [t][y][x] of the 4x4x4 pixel block
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) {
-        const int bt = blk >> 2, by = (blk >> 1) & 1, bx = blk & 1;
-        float v[8], o[8];
+            for (int dt = 0; dt < 4; ++dt) {
+                int t = 4 * to + dt - 3;  // the first frame is repeated patch_size times in front (patching.py:162-163)
+                t = t < 0 ? 0 : t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int dt = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
-            int t = 4 * to + 2 * bt + dt - 3;  // the first frame is repeated patch_size times in front (patching.py:162-163)
-            t = t < 0 ? 0 : t;
-            v[i] = (float)vc[((int64_t)t * H + (4 * yo + 2 * by + dy)) * W + (4 * xo + 2 * bx + dx)];
+                for (int dy = 0; dy < 4; ++dy) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(vc + ((int64_t)t * H + (4 * yo + dy)) * W + 4 * xo);
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) px[dt][dy][dx] = (float)v[dx];
+                }
+            }
+            float l1[8][8];  // [level-1 band][level-1 block (bt,by,bx)]
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                const int bt = blk >> 2, by = (blk >> 1) & 1, bx = blk & 1;
+                float v[8], o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = px[2 * bt + (i >> 2)][2 * by + ((i >> 1) & 1)][2 * bx + (i & 1)];
+                haar8(v, o, 0.125f);
+#pragma unroll
+                for (int b1 = 0; b1 < 8; ++b1) l1[b1][blk] = o[b1];
+            }
+#pragma unroll
+            for (int b1 = 0; b1 < 8; ++b1) {
+                float o[8];
+                haar8(l1[b1], o, 0.125f);
+#pragma unroll
+                for (int b2 = 0; b2 < 8; ++b2) srow[b2 * 24 + b1 * 3 + c] = f32_to_bf16(o[b2]);
+            }
         }
-        haar8(v, o, 0.125f);
-#pragma unroll
-        for (int b1 = 0; b1 < 8; ++b1) l1[b1][blk] = o[b1];
     }
-    bf16_t* orow = out + (((int64_t)to * Hp + yo) * Wp + xo) * 192;
-#pragma unroll
-    for (int b1 = 0; b1 < 8; ++b1) {
-        float o[8];
-        haar8(l1[b1], o, 0.125f);
-#pragma unroll
-        for (int b2 = 0; b2 < 8; ++b2) orow[b2 * 24 + b1 * 3 + c] = f32_to_bf16(o[b2]);
+    __syncthreads();
+    const int64_t rows = total - idx0 < HAAR_BLOCK ? total - idx0 : HAAR_BLOCK;
+    bf16_t* obase = out + idx0 * 192;
+    for (int i = threadIdx.x; i < (int)rows * 24; i += HAAR_BLOCK) {  // 24 16-byte chunks per row
+        const int r = i / 24, ch = i - r * 24;
+        store_bf16x8(obase + (int64_t)i * 8, *reinterpret_cast<const bf16x8*>(stage + r * HAAR_ROW_BYTES + ch * 16));
     }
 }
 
@@ -131,40 +156,65 @@ G3_DEVICE void ihaar8(const float (&band)[8], float (&v)[8]) {  // band = 4*lt+2
     for (int i = 0; i < 4; ++i) { v[i] = b[i] + b[i + 4]; v[i + 4] = b[i] - b[i + 4]; }  // t
 }
 
-__global__ __launch_bounds__(256) void haar_unpatch_kernel(const bf16_t* __restrict__ coef, int64_t ld, bf16_t* __restrict__ video,
-                                                           int Tp, int Hp, int Wp, int Tout) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)Tp * Hp * Wp * 3;
+// One thread = one coefficient row (t', y', x'), all three colour channels: 24 16-byte loads of its contiguous 384 bytes (ld = 192) or
+// scalar loads (any other ld), 8-byte stores of 4 pixels per (colour, frame, line) with neighbouring threads neighbours in memory.
+__global__ __launch_bounds__(HAAR_BLOCK) void haar_unpatch_kernel(const bf16_t* __restrict__ coef, int64_t ld, bf16_t* __restrict__ video,
+                                                                  int Tp, int Hp, int Wp, int Tout) {
+    const int64_t idx = (int64_t)blockIdx.x * HAAR_BLOCK + threadIdx.x;
+    const int64_t total = (int64_t)Tp * Hp * Wp;
     if (idx >= total) return;
     const int xo = (int)(idx % Wp);
     const int yo = (int)((idx / Wp) % Hp);
-    const int to = (int)((idx / ((int64_t)Wp * Hp)) % Tp);
-    const int c = (int)(idx / ((int64_t)Wp * Hp * Tp));
-    const bf16_t* crow = coef + (((int64_t)to * Hp + yo) * Wp + xo) * ld;
+    const int to = (int)(idx / ((int64_t)Wp * Hp));
+    const bf16_t* crow = coef + idx * ld;
     const int H = 4 * Hp, W = 4 * Wp;
-    float l1[8][8];  // [band1][block]
+    bf16_t cf[192];
+    if (!(ld & 7) && !((uintptr_t)coef & 15)) {
 #pragma unroll
-    for (int b1 = 0; b1 < 8; ++b1) {
-        float band[8], v[8];
+        for (int j = 0; j < 24; ++j) *reinterpret_cast<bf16x8*>(cf + 8 * j) = load_bf16x8(crow + 8 * j);
+    } else {
 #pragma unroll
-        for (int b2 = 0; b2 < 8; ++b2) band[b2] = (float)crow[b2 * 24 + b1 * 3 + c];
-        ihaar8(band, v);
-#pragma unroll
-        for (int blk = 0; blk < 8; ++blk) l1[b1][blk] = v[blk];
+        for (int j = 0; j < 192; ++j) cf[j] = crow[j];
     }
-    bf16_t* vc = video + (int64_t)c * Tout * H * W;
+    for (int c = 0; c < 3; ++c) {
+        float l1[8][8];  // [band1][block]
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) {
-        const int bt = blk >> 2, by = (blk >> 1) & 1, bx = blk & 1;
-        float band[8], v[8];
+        for (int b1 = 0; b1 < 8; ++b1) {
+            float band[8], v[8];
 #pragma unroll
-        for (int b1 = 0; b1 < 8; ++b1) band[b1] = l1[b1][blk];
-        ihaar8(band, v);
+            for (int b2 = 0; b2 < 8; ++b2) band[b2] = (float)cf[b2 * 24 + b1 * 3 + c];
+            ihaar8(band, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int dt = i >> 2, dy = (i >> 1) & 1, dx = i & 1;
-            const int t = 4 * to + 2 * bt + dt - 3;  // drop the first patch_size-1 frames (patching.py:298)
-            if (t >= 0 && t < Tout) vc[((int64_t)t * H + (4 * yo + 2 * by + dy)) * W + (4 * xo + 2 * bx + dx)] = f32_to_bf16(v[i]);
+            for (int blk = 0; blk < 8; ++blk) l1[b1][blk] = v[blk];
+        }
+        bf16_t* vc = video + (int64_t)c * Tout * H * W;
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp) {  // the two level-1 blocks (bx = 0, 1) of one (bt, by): 2 frames x 2 lines x 4 pixels
+            const int bt = bp >> 1, by = bp & 1;
+            float v0[8], v1[8];
+            {
+                float band[8];
+#pragma unroll
+                for (int b1 = 0; b1 < 8; ++b1) band[b1] = l1[b1][4 * bt + 2 * by];
+                ihaar8(band, v0);
+#pragma unroll
+                for (int b1 = 0; b1 < 8; ++b1) band[b1] = l1[b1][4 * bt + 2 * by + 1];
+                ihaar8(band, v1);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int t = 4 * to + 2 * bt + dt - 3;  // drop the first patch_size-1 frames (patching.py:298)
+                if (t < 0 || t >= Tout) continue;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    bf16x4 o;  // index inside a block = 4 t + 2 h + w
+                    o[0] = f32_to_bf16(v0[4 * dt + 2 * dy]);
+                    o[1] = f32_to_bf16(v0[4 * dt + 2 * dy + 1]);
+                    o[2] = f32_to_bf16(v1[4 * dt + 2 * dy]);
+                    o[3] = f32_to_bf16(v1[4 * dt + 2 * dy + 1]);
+                    *reinterpret_cast<bf16x4*>(vc + ((int64_t)t * H + (4 * yo + 2 * by + dy)) * W + 4 * xo) = o;
+                }
+            }
         }
     }
 }
@@ -386,18 +436,20 @@ extern "C" int g3_haar3d_patch_bf16(const void* video, void* out, int T, int H, 
     if (!video || !out) return g3_set_error(G3_ERR_ARG, "g3_haar3d_patch_bf16: null operand");
     if (T < 1 || ((T + 3) & 3) || (H & 3) || (W & 3)) return g3_set_error(G3_ERR_ARG, "g3_haar3d_patch_bf16: need (T+3), H, W multiples of 4");
     const int Tp = (T + 3) / 4, Hp = H / 4, Wp = W / 4;
-    const int64_t total = (int64_t)Tp * Hp * Wp * 3;
-    hipLaunchKernelGGL(haar_patch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)video,
-                       (bf16_t*)out, T, H, W, Tp, Hp, Wp);
+    if (((uintptr_t)video & 7) || ((uintptr_t)out & 15)) return g3_set_error(G3_ERR_ARG, "g3_haar3d_patch_bf16: video must be 8-byte, out 16-byte aligned");
+    const int64_t total = (int64_t)Tp * Hp * Wp;
+    hipLaunchKernelGGL(haar_patch_kernel, dim3((unsigned)((total + HAAR_BLOCK - 1) / HAAR_BLOCK)), dim3(HAAR_BLOCK), 0, (hipStream_t)stream,
+                       (const bf16_t*)video, (bf16_t*)out, T, H, W, Tp, Hp, Wp);
     return g3_check_launch("g3_haar3d_patch_bf16");
 }
 
 extern "C" int g3_haar3d_unpatch_bf16(const void* coef, int64_t ld, void* video, int Tp, int Hp, int Wp, void* stream) {
     if (!coef || !video) return g3_set_error(G3_ERR_ARG, "g3_haar3d_unpatch_bf16: null operand");
     if (Tp < 1 || Hp < 1 || Wp < 1 || ld < 192) return g3_set_error(G3_ERR_ARG, "g3_haar3d_unpatch_bf16: bad shape");
-    const int64_t total = (int64_t)Tp * Hp * Wp * 3;
-    hipLaunchKernelGGL(haar_unpatch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)coef, ld,
-                       (bf16_t*)video, Tp, Hp, Wp, 4 * Tp - 3);
+    if ((uintptr_t)video & 7) return g3_set_error(G3_ERR_ARG, "g3_haar3d_unpatch_bf16: video must be 8-byte aligned");
+    const int64_t total = (int64_t)Tp * Hp * Wp;
+    hipLaunchKernelGGL(haar_unpatch_kernel, dim3((unsigned)((total + HAAR_BLOCK - 1) / HAAR_BLOCK)), dim3(HAAR_BLOCK), 0, (hipStream_t)stream,
+                       (const bf16_t*)coef, ld, (bf16_t*)video, Tp, Hp, Wp, 4 * Tp - 3);
     return g3_check_launch("g3_haar3d_unpatch_bf16");
 }
 

@@ -493,7 +493,10 @@ def test_flash_attn_split_kv_partials_merge(variant, S_local, world, rank, B, H)
     """Split-KV attention: the keys of a row are covered by several launches that return a normalised fp32 partial +
     log-sum-exp each (g3_flash_attn_fwd_ex_bf16), merged by g3_attn_merge_partials_bf16. Layout as under context parallelism: K gathered
     rank-major, V^T in per-rank key segments; parts = this rank's own shard, the ranks before it, the ranks after it. Must match the
-    single call over all keys (<= 3e-3: one extra rounding pattern, fp32 partials) and an fp32 softmax (<= 1e-2, the attention tolerance)."""
+    single call over all keys and an fp32 softmax. Tolerances: vs fp32 <= 4e-3 - the bound the single call itself is held to
+    (tests/test_fullsize_gpu.py; measured 2.9e-3 for both) - and no worse than the single call's own error + 10 %; vs the single call <= 4.5e-3:
+    the two results carry INDEPENDENT bf16 roundings of P (each launch rounds relative to its own running maximum), so their distance is
+    ~sqrt(2) x the distance of either to fp32 (measured 2.9e-3 .. 3.3e-3), exactly as for a permutation of the keys."""
     from gen3c_amd import ops
     dev = _dev()
     S_all = S_local * world
@@ -510,15 +513,17 @@ def test_flash_attn_split_kv_partials_merge(variant, S_local, world, rank, B, H)
             parts.append(ops.flash_attn(q, k[r0 * rows:r1 * rows], vt_seg[r0:r1].contiguous(), S_local, (r1 - r0) * S_local, B, H, variant=variant, partial=True))
     merged = ops.attn_merge(parts, S_local, B, H)
     r_split = _rel_l2(merged, full)
-    worst = 0.0
+    worst = worst_full = 0.0
     for b in range(B):
         for h in range(H):
             sl = slice(h * 128, (h + 1) * 128)
             sc = (q[b::B, sl].float() @ k[b::B, sl].float().t()) / math.sqrt(128)
             ref = torch.softmax(sc, dim=-1) @ v[b::B, sl].float()
             worst = max(worst, _rel_l2(merged[b::B, sl], ref))
-    print(f"[split-kv v{variant} S_local={S_local} world={world} rank={rank} B={B} H={H}] {len(parts)} parts: vs one call {r_split:.3e}, vs fp32 {worst:.3e}")
-    assert r_split <= 3e-3 and worst <= 1e-2
+            worst_full = max(worst_full, _rel_l2(full[b::B, sl], ref))
+    print(f"[split-kv v{variant} S_local={S_local} world={world} rank={rank} B={B} H={H}] {len(parts)} parts: vs one call {r_split:.3e}, "
+          f"vs fp32 {worst:.3e} (single call vs fp32 {worst_full:.3e})")
+    assert r_split <= 4.5e-3 and worst <= 4e-3 and worst <= 1.1 * worst_full
     # a single part merged alone is the plain result (weights = 1): fp32 partial -> bf16 once
     one = ops.attn_merge([ops.flash_attn(q, k, vt_seg, S_local, S_all, B, H, variant=variant, partial=True)], S_local, B, H)
     assert _rel_l2(one, full) <= 1e-6 or torch.equal(one, full)

@@ -143,7 +143,7 @@ def _chain(n_buffers: int, guidance: float, num_steps: int):
 def test_single_image_chunk_end_to_end():
     psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=3)
     print(f"[e2e] decoded video: minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (worst-frame mse {mse:.2e})")
-    assert psnr >= 33.0  # whole-clip value measured 37.5 dB
+    assert psnr >= 35.5  # measured: worst frame 37.3 dB (frames 37.3 .. 37.6)
 
 
 def test_two_buffers_guidance_end_to_end():
@@ -151,16 +151,16 @@ def test_two_buffers_guidance_end_to_end():
     buffers of one target frame) and classifier-free guidance 1.5 (c + g (c - u) with a negative prompt and zeroed pose)."""
     psnr, mse = _chain(n_buffers=2, guidance=1.5, num_steps=3)
     print(f"[e2e N=2 g=1.5] decoded video minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
-    assert psnr >= 33.0  # measured 37.6 dB
+    assert psnr >= 35.5  # measured: worst frame 36.9 dB (frames 36.9 .. 37.7)
 
 
 def test_full_schedule_trajectory_drift():
     """All 35 steps of the Karras schedule on the tiny model (sigma 80 -> 0.0002, incl. the indicator-off tail and sigma_next = 0):
-    the bf16 HIP trajectory must stay within a stated distance of the fp32 oracle trajectory - drift bound: decoded PSNR >= 33 dB
-    (measured 37.4 dB, the same as after 3 steps: 37.5 dB - no accumulation over the schedule)."""
+    the bf16 HIP trajectory must stay within a stated distance of the fp32 oracle trajectory - drift bound: worst-frame PSNR >= 35.5 dB
+    (measured 37.3 dB, the same as after 3 steps: 37.5 dB - no accumulation over the schedule)."""
     psnr, mse = _chain(n_buffers=1, guidance=1.0, num_steps=35)
     print(f"[e2e 35 steps] decoded video minimum per-frame PSNR vs fp32 oracle chain: {psnr:.1f} dB (mse {mse:.2e})")
-    assert psnr >= 33.0
+    assert psnr >= 35.5  # measured: worst frame 37.3 dB (frames 37.3 .. 38.1)
 
 
 def test_fused_cond_uncond_forward_is_bitwise_the_two_call_form():
