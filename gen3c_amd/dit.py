@@ -24,8 +24,24 @@ from torch import nn
 from . import ops
 from .parallel import ContextParallelAttention, split_inputs_cp
 
-# 0: run the per-head RMSNorm + RoPE and the V transpose as separate passes instead of in the QKV projection's epilogue (A/B switch)
-_FUSE_QKV_EPILOGUE = __import__("os").environ.get("G3_FUSE_QKV_EPILOGUE", "1") != "0"
+# 1: run the per-head RMSNorm + RoPE and the V transpose in the QKV projection's epilogue (g3_gemm_qk_norm_rope_bf16) instead of as separate
+# HBM-bound passes behind a plain GEMM. Measured in one process at the benchmark shape (tools/qkv_probe.py, profiles/r3_qkv_probe.txt):
+# B = 2: plain GEMM 8.23 ms; GEMM + 2 norm passes + transpose 9.21 ms; fused 11.85 ms - at one wave per SIMD nothing overlaps the
+# epilogue's VALU work and table reads, so the separate passes (0.98 ms at the HBM rate) are the default since round 3 (+2 % on the step).
+_FUSE_QKV_EPILOGUE = __import__("os").environ.get("G3_FUSE_QKV_EPILOGUE", "0") != "0"
+
+
+def _project_norm_rope(h, w, n_q, n_k, norm_q, norm_k, cos, sin, S, B, nH_total):
+    """a @ w^T with per-head RMSNorm (+ RoPE) on the first n_q (weight norm_q) and the next n_k (norm_k) output features; the rest plain.
+    Same rounding points either way (tested): the fused GEMM epilogue, or the plain GEMM followed by the in-place norm passes."""
+    if _FUSE_QKV_EPILOGUE:
+        return ops.gemm_qk_norm_rope(h, w, n_q, n_k, norm_q, norm_k, cos, sin, S, B)
+    y = ops.gemm_nt(h, w)
+    if n_q:
+        ops.qk_rmsnorm_rope(y[:, :n_q], norm_q, cos, sin, S, B, n_q // 128, out=y[:, :n_q])
+    if n_k:
+        ops.qk_rmsnorm_rope(y[:, n_q:n_q + n_k], norm_k, cos, sin, S, B, n_k // 128, out=y[:, n_q:n_q + n_k])
+    return y
 
 
 class DataType(Enum):
@@ -432,9 +448,9 @@ class VideoExtendGeneralDIT(nn.Module):
                 # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
                 # every output element sees the same K order, so this is bit-identical to the single fused GEMM)
                 # the per-head RMSNorm + RoPE of q and k (attention.py:262-280) run in the projections' epilogues
-                kv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"][D:], 0, D, None, blk["fa_kn"], cos, sin, S, B)  # [S*B, 2D]: k normalised + rotated, v plain
+                kv = _project_norm_rope(h, blk["fa_qkv"][D:], 0, D, None, blk["fa_kn"], cos, sin, S, B, nH)  # [S*B, 2D]: k normalised + rotated, v plain
                 pending = self._cp_attn.start(kv[:, :D], kv[:, D:], S, B, nH)
-                q = ops.gemm_qk_norm_rope(h, blk["fa_qkv"][:D], D, 0, blk["fa_qn"], None, cos, sin, S, B)
+                q = _project_norm_rope(h, blk["fa_qkv"][:D], D, 0, blk["fa_qn"], None, cos, sin, S, B, nH)
                 o = self._cp_attn.finish(q, pending)
             else:
                 if _FUSE_QKV_EPILOGUE:
@@ -442,17 +458,17 @@ class VideoExtendGeneralDIT(nn.Module):
                     vt = self._vt_buffer(S, B, nH, dev)
                     qkv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B, vt=vt)
                     q, k = qkv[:, :D], qkv[:, D:2 * D]
-                else:  # the separate passes (A/B: tools / DESIGN.md; 2-3 % faster on this one op, 0.2 % of the step)
+                else:  # plain GEMM, then q / k normalised + rotated IN PLACE in the fused buffer and v transposed (the default: see _FUSE_QKV_EPILOGUE)
                     qkv = ops.gemm_nt(h, blk["fa_qkv"])
-                    q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH)
-                    k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH)
-                    vt = ops.transpose_v(qkv[:, 2 * D:], S, B, nH)
+                    q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH, out=qkv[:, :D])
+                    k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH, out=qkv[:, D:2 * D])
+                    vt = ops.transpose_v(qkv[:, 2 * D:], S, B, nH, out=self._vt_buffer(S, B, nH, dev))
                 o = ops.flash_attn(q, k, vt, S, S, B, nH)
             ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- cross attention (unmasked over all M context tokens, general_dit.py:407-410)
             shift, scale, gate = self._modulation(emb, blk["ada"][1], adaln_lora, 3)
             h = ops.layernorm_modulate(xs, shift, scale)
-            q = ops.gemm_qk_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B)
+            q = _project_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B, nH)
             k, vt = ca_kv[bi]
             o = ops.flash_attn(q, k, vt, S, M, B, nH)
             ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
