@@ -56,6 +56,9 @@ SIGNATURES = {
     "g3_align_depth_workspace_bytes": [i32, i32],
     "g3_align_depth_f32": [vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, C.c_size_t, i32, i32, vp],
     "g3_conv3d_cl_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64] + [i32] * 17 + [vp],
+    "g3_conv3d_cl_gnstats_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64] + [i32] * 17 + [vp, i32, vp],
+    "g3_groupnorm_stats_cl_bf16": [vp, i64, vp, i32, i32, i32, vp],
+    "g3_groupnorm_apply_cl_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
     "g3_groupnorm_swish_cl_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
     "g3_haar3d_patch_bf16": [vp, vp, i32, i32, i32, vp],
     "g3_haar3d_unpatch_bf16": [vp, i64, vp, i32, i32, i32, vp],

@@ -44,7 +44,7 @@ struct ConvGeom {
     int ntaps;
     int64_t w_tap_stride;  // elements between consecutive tap slabs of W
 };
-__device__ __attribute__((aligned(16))) unsigned g3_zero_page[64];  // 256 zero bytes: source of padded taps on the LDS-DMA path
+__device__ __attribute__((aligned(16))) unsigned g3_zero_page[2048];  // 8 KiB of zeros: source of padded taps on the LDS-DMA path (the one-wave kernel walks up to K * 2 bytes into it)
 
 struct GemmParams {
     int tile_order_rowmajor;
@@ -60,6 +60,8 @@ struct GemmParams {
     // EPI_QK_NORM_ROPE: features [0, n_q) are q heads (weight nw_q), [n_q, n_q + n_k) k heads (nw_k), the rest is stored as is
     const bf16_t* nw_q; const bf16_t* nw_k; const float* rope_cos; const float* rope_sin; int n_q, n_k, rope_B; float rms_eps;
     bf16_t* vt; int64_t vt_ld, vt_batch; int vt_S;  // optional V^T destination of the remaining (v) heads: [B][H_v][128][vt_ld], S valid positions
+    // gemm_w4_conv.hpp: optional GroupNorm statistics of the output ([frames][2] doubles: sum, sum of squares; frame = gn_rows consecutive rows)
+    double* gn_stats = nullptr; int gn_rows = 0;
 };
 
 G3_DEVICE int lds_off(int row, int chunk) {  // element offset in a [rows][64] bf16 tile
@@ -747,10 +749,22 @@ int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
 }
 
 #include "gemm_w4.hpp"
+#include "gemm_w4_conv.hpp"
+
+// CONV on the one-wave-per-SIMD kernel (gemm_w4_conv.hpp): whole 64-channel tiles, >= 2 K tiles, K * 2 bytes inside the zero page,
+// <= 32 spatial taps (bit masks), full-line epilogue, activation span addressable with 32-bit row * lda products
+static bool conv_w4_applies(const GemmParams& p) {
+    const int64_t in_rows = (int64_t)p.cv.Ti * p.cv.Hi * p.cv.Wi;
+    return g3_opt_conv_w4 && (p.K % BK) == 0 && !g3_opt_gemm_regstage && p.wide_store && (p.K / BK) * p.cv.ntaps >= 2 && p.K * 2 <= G3_ZERO_PAGE_BYTES &&
+           p.cv.kh * p.cv.kw <= 32 && in_rows < (1ll << 31) && p.lda * 2 < (1ll << 31);
+}
 
 template <int EPI, bool CONV>
 int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
+    if constexpr (CONV && (EPI == EPI_NONE || EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL)) {
+        if (conv_w4_applies(p)) return launch_w4_conv<EPI>(p, stream, what);
+    }
     if constexpr (!CONV) {  // one wave per SIMD (gemm_w4.hpp): whole 64-wide K tiles, at least two, full-line epilogue
         if (glds && g3_opt_gemm_pingpong == 3 && p.wide_store && p.K >= 2 * BK) return launch_w4<EPI>(p, stream, what);
     }
@@ -868,9 +882,11 @@ extern "C" int g3_gemm_qk_norm_rope_bf16(const void* A, int64_t lda, const void*
 // Causal 3-D convolution as an implicit GEMM over channels-last activations.
 //   in  [Ti*Hi*Wi][ld_in]  (C_in = K valid channels per position), w [kt*kh*kw][N][ldw] (tap-major, K contiguous),
 //   out [To*Ho*Wo][ld_out]; bias [N] (may be NULL), residual [To*Ho*Wo][ldr] (may be NULL) added after the bias.
-extern "C" int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
-                                 int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho,
-                                 int Wo, int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* stream) {
+extern "C" int g3_groupnorm_stats_cl_bf16(const void* x, int64_t ld, void* stats_f64, int frames, int rows_per_frame, int C, void* stream);
+
+static int conv3d_cl(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                     int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho,
+                     int Wo, int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, double* gn_stats, int gn_rows, void* stream) {
     if (!in || !w || !out) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: null operand");
     if (K <= 0 || N <= 0 || (K & 7) || (ld_in & 7) || (ldw & 7) || (N & 3) || (ld_out & 3))
         return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_bf16: need K, ld_in, ldw %% 8 == 0 and N, ld_out %% 4 == 0 (K=%d N=%d)", K, N);
@@ -892,7 +908,36 @@ extern "C" int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, i
     p.cv = ConvGeom{To, Ho, Wo, Ti, Hi, Wi, kt, kh, kw, st, sh, sw, ot, oh, ow, kt * kh * kw, (int64_t)N * ldw};
     hipStream_t s = (hipStream_t)stream;
     const char* what = "g3_conv3d_cl_bf16";
-    if (residual) return launch<EPI_BIAS_RESIDUAL, true>(p, s, what);
-    if (bias) return launch<EPI_BIAS, true>(p, s, what);
-    return launch<EPI_NONE, true>(p, s, what);
+    // GroupNorm statistics of the output: in the one-wave kernel's epilogue when it runs (and a frame is at least one wave quadrant of rows),
+    // else by the statistics pass over the finished output
+    const bool fuse_stats = gn_stats && gn_rows >= 128 && conv_w4_applies(p);
+    if (fuse_stats) { p.gn_stats = gn_stats; p.gn_rows = gn_rows; }
+    int rc;
+    if (residual) rc = launch<EPI_BIAS_RESIDUAL, true>(p, s, what);
+    else if (bias) rc = launch<EPI_BIAS, true>(p, s, what);
+    else rc = launch<EPI_NONE, true>(p, s, what);
+    if (rc == G3_OK && gn_stats && !fuse_stats) {
+        if (gn_rows <= 0 || (p.M % gn_rows)) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_gnstats_bf16: gn_rows_per_frame must divide the output rows");
+        rc = g3_groupnorm_stats_cl_bf16(out, ld_out, gn_stats, p.M / gn_rows, gn_rows, N, stream);
+    }
+    return rc;
+}
+
+extern "C" int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                                 int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho,
+                                 int Wo, int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* stream) {
+    return conv3d_cl(in, ld_in, w, ldw, bias, residual, ldr, out, ld_out, K, N, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw, st, sh, sw, ot, oh, ow, nullptr, 0, stream);
+}
+
+// Same convolution; additionally ADDS, per output frame (gn_rows_per_frame consecutive output rows = Ho * Wo), the sum and the sum of squares of
+// the stored bf16 outputs to gn_stats[frame][0 / 1] (doubles; the caller zeroes them): the statistics CausalNormalize needs of this tensor
+// (tokenizer/modules/utils.py:58-83), so that the following g3_groupnorm_apply_cl_bf16 does not have to read the tensor twice.
+extern "C" int g3_conv3d_cl_gnstats_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                                         int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho,
+                                         int Wo, int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* gn_stats_f64,
+                                         int gn_rows_per_frame, void* stream) {
+    if (!gn_stats_f64 || gn_rows_per_frame <= 0 || ((uintptr_t)gn_stats_f64 & 7)) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_gnstats_bf16: bad statistics buffer");
+    if (((int64_t)To * Ho * Wo) % gn_rows_per_frame) return g3_set_error(G3_ERR_ARG, "g3_conv3d_cl_gnstats_bf16: gn_rows_per_frame must divide the output rows");
+    return conv3d_cl(in, ld_in, w, ldw, bias, residual, ldr, out, ld_out, K, N, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw, st, sh, sw, ot, oh, ow,
+                     (double*)gn_stats_f64, gn_rows_per_frame, stream);
 }

@@ -60,14 +60,23 @@ struct GW4Pieces {  // up to 6 pieces per k-step statement: LDS destination, per
     uint32_t m[6];
     uint32_t vo[6];
     const char* sb[6];
+    uint64_t va[6];  // implicit-GEMM convolution (gemm_w4_conv.hpp): token pieces carry a full per-lane address instead of base + offset
 };
+// LDS-DMA piece whose source is a per-lane 64-bit address (gathered activation rows of a convolution tap, or the zero page)
+#if G3_AB_GW4_ABLATE & 4
+#define GW4_LDV(Q) ""
+#else
+#define GW4_LDV(Q) "global_load_lds_dwordx4 %[va" #Q "], off\n\t"
+#endif
 
 // One k-step: wait for this k-step's fragments (buffer KS & 1), 16 MFMAs; between them the 8 fragment reads of the next k-step (other buffer)
 // when READ, and NP (0, 5 or 6) LDS-DMA pieces spread evenly over the MFMA gaps: four waves issuing one 1 KiB piece per ~3 MFMAs ask the
 // vector memory path for ~43 B/clk/CU (its peak is 64) - issued back to back (8 per k-step, round 2's first form) they queue up and the
 // issue stall lands on the only wave that can feed the matrix pipe.
 // BAR: behind the MFMAs wait for all LDS reads and LDS-DMA of this wave and join the workgroup barrier.
-template <int KS, bool READ, int NP, bool BAR>
+// PT (NP == 5 only): 0 = every piece base + offset; 1 = pieces 0, 1 base + offset (weights), 2..4 per-lane addresses (conv token rows); 2 = all five
+// per-lane addresses.
+template <int KS, bool READ, int NP, bool BAR, int PT = 0>
 G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
     constexpr int cur = GW4_FRAG0 + 32 * (KS & 1), nxt = GW4_FRAG0 + 32 * ((KS & 1) ^ 1);
 #define GW4_OPS_MM(I, J) [d##I##J] "n"(16 * (4 * J + I)), [z##I##J] "n"(16 * (4 * J + I) + 15)
@@ -82,6 +91,7 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
                    [o0] "n"(0), [o1] "n"(4096), [o2] "n"(8192), [o3] "n"(12288), [o4] "n"(GW4_T_OFF), [o5] "n"(GW4_T_OFF + 4096), [o6] "n"(GW4_T_OFF + 8192), \
                    [o7] "n"(GW4_T_OFF + 12288)
 #define GW4_OPS_P(Q) [m##Q] "s"(pc.m[Q]), [vo##Q] "v"(pc.vo[Q]), [sb##Q] "s"(pc.sb[Q])
+#define GW4_OPS_PV(Q) [m##Q] "s"(pc.m[Q]), [va##Q] "v"(pc.va[Q])
 #if G3_AB_GW4_ABLATE & 2
 #define GW4_BARRIER "s_waitcnt lgkmcnt(0)\n\t"
 #elif G3_AB_GW4_ABLATE & 1
@@ -97,13 +107,27 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
                      GW4_MM(0, 2) GW4_M0(3) GW4_MM(1, 2) GW4_LD(3) GW4_MM(2, 2) GW4_MM(3, 2) GW4_M0(4)
                      GW4_MM(0, 3) GW4_LD(4) GW4_MM(1, 3) GW4_M0(5) GW4_MM(2, 3) GW4_LD(5) GW4_MM(3, 3)
                      : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_P(0), GW4_OPS_P(1), GW4_OPS_P(2), GW4_OPS_P(3), GW4_OPS_P(4), GW4_OPS_P(5) : GW4_OWNED, "memory");
-    else if constexpr (READ && NP == 5 && !BAR)
+    else if constexpr (READ && NP == 5 && !BAR && PT == 0)
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      GW4_MM(0, 0) GW4_RD(N, 4) GW4_M0(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_LD(0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7) GW4_M0(1)
                      GW4_MM(0, 1) GW4_RD(N, 0) GW4_LD(1) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_M0(2) GW4_MM(3, 1) GW4_RD(N, 3) GW4_LD(2)
                      GW4_MM(0, 2) GW4_MM(1, 2) GW4_M0(3) GW4_MM(2, 2) GW4_LD(3) GW4_MM(3, 2)
                      GW4_MM(0, 3) GW4_M0(4) GW4_MM(1, 3) GW4_LD(4) GW4_MM(2, 3) GW4_MM(3, 3)
                      : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_P(0), GW4_OPS_P(1), GW4_OPS_P(2), GW4_OPS_P(3), GW4_OPS_P(4) : GW4_OWNED, "memory");
+    else if constexpr (READ && NP == 5 && !BAR && PT == 1)  // same stream, pieces 2..4 gathered by per-lane address
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_M0(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_LD(0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7) GW4_M0(1)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_LD(1) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_M0(2) GW4_MM(3, 1) GW4_RD(N, 3) GW4_LDV(2)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_M0(3) GW4_MM(2, 2) GW4_LDV(3) GW4_MM(3, 2)
+                     GW4_MM(0, 3) GW4_M0(4) GW4_MM(1, 3) GW4_LDV(4) GW4_MM(2, 3) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_P(0), GW4_OPS_P(1), GW4_OPS_PV(2), GW4_OPS_PV(3), GW4_OPS_PV(4) : GW4_OWNED, "memory");
+    else if constexpr (READ && NP == 5 && !BAR && PT == 2)  // all five gathered by per-lane address
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     GW4_MM(0, 0) GW4_RD(N, 4) GW4_M0(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_LDV(0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7) GW4_M0(1)
+                     GW4_MM(0, 1) GW4_RD(N, 0) GW4_LDV(1) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_M0(2) GW4_MM(3, 1) GW4_RD(N, 3) GW4_LDV(2)
+                     GW4_MM(0, 2) GW4_MM(1, 2) GW4_M0(3) GW4_MM(2, 2) GW4_LDV(3) GW4_MM(3, 2)
+                     GW4_MM(0, 3) GW4_M0(4) GW4_MM(1, 3) GW4_LDV(4) GW4_MM(2, 3) GW4_MM(3, 3)
+                     : : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, GW4_OPS_PV(0), GW4_OPS_PV(1), GW4_OPS_PV(2), GW4_OPS_PV(3), GW4_OPS_PV(4) : GW4_OWNED, "memory");
     else if constexpr (READ && NP == 0 && !BAR)
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)

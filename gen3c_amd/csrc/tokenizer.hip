@@ -432,6 +432,31 @@ extern "C" int g3_groupnorm_swish_cl_bf16(const void* x, int64_t ld, const void*
     return g3_check_launch("g3_groupnorm_swish_cl_bf16");
 }
 
+// The two halves of g3_groupnorm_swish_cl_bf16 as separate calls: statistics ADDED to stats_f64 (caller zeroes; g3_conv3d_cl_gnstats_bf16
+// produces the same numbers in the producing convolution's epilogue), and the normalisation given finished statistics.
+extern "C" int g3_groupnorm_stats_cl_bf16(const void* x, int64_t ld, void* stats_f64, int frames, int rows_per_frame, int C, void* stream) {
+    if (!x || !stats_f64) return g3_set_error(G3_ERR_ARG, "g3_groupnorm_stats_cl_bf16: null operand");
+    if (frames <= 0 || rows_per_frame <= 0 || C <= 0 || (C & 7) || (ld & 7)) return g3_set_error(G3_ERR_ARG, "g3_groupnorm_stats_cl_bf16: C, ld must be multiples of 8");
+    const int64_t chunks = (int64_t)rows_per_frame * (C >> 3);
+    int gx = (int)((chunks + 256 * 8 - 1) / (256 * 8));
+    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, frames), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows_per_frame, C, (double*)stats_f64);
+    return g3_check_launch("g3_groupnorm_stats_cl_bf16");
+}
+
+extern "C" int g3_groupnorm_apply_cl_bf16(const void* x, int64_t ld, const void* gamma, const void* beta, const void* stats_f64, void* out,
+                                          int64_t ldo, int frames, int rows_per_frame, int C, float eps, int swish, void* stream) {
+    if (!x || !gamma || !beta || !stats_f64 || !out) return g3_set_error(G3_ERR_ARG, "g3_groupnorm_apply_cl_bf16: null operand");
+    if (frames <= 0 || rows_per_frame <= 0 || C <= 0 || (C & 7) || (ld & 7) || (ldo & 7))
+        return g3_set_error(G3_ERR_ARG, "g3_groupnorm_apply_cl_bf16: C, ld, ldo must be multiples of 8");
+    const int64_t chunks = (int64_t)rows_per_frame * (C >> 3);
+    int gx = (int)((chunks + 256 * 8 - 1) / (256 * 8));
+    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, frames), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, (const bf16_t*)gamma, (const bf16_t*)beta,
+                       (const double*)stats_f64, (bf16_t*)out, ldo, rows_per_frame, C, eps, swish);
+    return g3_check_launch("g3_groupnorm_apply_cl_bf16");
+}
+
 extern "C" int g3_haar3d_patch_bf16(const void* video, void* out, int T, int H, int W, void* stream) {
     if (!video || !out) return g3_set_error(G3_ERR_ARG, "g3_haar3d_patch_bf16: null operand");
     if (T < 1 || ((T + 3) & 3) || (H & 3) || (W & 3)) return g3_set_error(G3_ERR_ARG, "g3_haar3d_patch_bf16: need (T+3), H, W multiples of 4");

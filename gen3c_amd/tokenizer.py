@@ -20,6 +20,8 @@ import torch
 from . import _lib, ops
 
 bf16 = torch.bfloat16
+# 0: GroupNorm statistics always by their own pass over the tensor (A/B switch; default: produced in the epilogue of the convolution that writes it)
+_FUSE_GN_STATS = os.environ.get("G3_FUSE_GN_STATS", "1") != "0"
 
 
 def _st() -> int:
@@ -151,7 +153,9 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         return sd
 
     # ------------------------------------------------------------------------------------------------ primitive calls
-    def _conv(self, x: torch.Tensor, name: str, kind: str, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _conv(self, x: torch.Tensor, name: str, kind: str, residual: Optional[torch.Tensor] = None, stats: bool = False) -> torch.Tensor:
+        """stats=True: the output is the input of a CausalNormalize - its per-frame GroupNorm statistics are produced with the convolution
+        (g3_conv3d_cl_gnstats_bf16: in the kernel's epilogue) and kept for the _gn call that consumes this very tensor."""
         w, b = self._w[f"{name}.conv3d.weight"], self._w[f"{name}.conv3d.bias"]
         kt, kh, kw, st, sh, sw, ot, oh, ow = _GEOM[kind]
         assert w.shape[0] == kt * kh * kw, f"{name}: weight taps {w.shape[0]} vs geometry {kind}"
@@ -167,18 +171,30 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         if residual is not None:
             assert residual.shape == out.shape and residual.is_contiguous()
         lib = _lib.load()
-        _lib.check(lib.g3_conv3d_cl_bf16(_ptr(x), K, _ptr(w), K, _ptr(b), _ptr(residual), N, _ptr(out), N, K, N, Ti, Hi, Wi, To, Ho, Wo,
-                                         kt, kh, kw, st, sh, sw, ot, oh, ow, _st()), f"g3_conv3d_cl_bf16({name})")
+        geom = (K, N, Ti, Hi, Wi, To, Ho, Wo, kt, kh, kw, st, sh, sw, ot, oh, ow)
+        if stats and _FUSE_GN_STATS:
+            st64 = torch.zeros((To, 2), dtype=torch.float64, device=x.device)
+            _lib.check(lib.g3_conv3d_cl_gnstats_bf16(_ptr(x), K, _ptr(w), K, _ptr(b), _ptr(residual), N, _ptr(out), N, *geom, _ptr(st64), Ho * Wo, _st()),
+                       f"g3_conv3d_cl_gnstats_bf16({name})")
+            self._pending_stats = (out, st64)  # consumed by the next _gn of `out` (held by reference: the address cannot be recycled meanwhile)
+        else:
+            _lib.check(lib.g3_conv3d_cl_bf16(_ptr(x), K, _ptr(w), K, _ptr(b), _ptr(residual), N, _ptr(out), N, *geom, _st()), f"g3_conv3d_cl_bf16({name})")
         return out
 
     def _gn(self, x: torch.Tensor, name: str, swish: bool) -> torch.Tensor:
         T, H, W, C = x.shape
         out = torch.empty_like(x)
-        stats = torch.empty((T, 2), dtype=torch.float64, device=x.device)
         lib = _lib.load()
-        _lib.check(lib.g3_groupnorm_swish_cl_bf16(_ptr(x), C, _ptr(self._w[f"{name}.norm.weight"]), _ptr(self._w[f"{name}.norm.bias"]),
-                                                  _ptr(stats), _ptr(out), C, T, H * W, C, 1e-6, 1 if swish else 0, _st()),
-                   f"g3_groupnorm_swish_cl_bf16({name})")
+        gamma, beta = self._w[f"{name}.norm.weight"], self._w[f"{name}.norm.bias"]
+        pend = getattr(self, "_pending_stats", None)
+        if pend is not None and pend[0] is x:  # the producing convolution already delivered the statistics: one pass over x
+            self._pending_stats = None
+            _lib.check(lib.g3_groupnorm_apply_cl_bf16(_ptr(x), C, _ptr(gamma), _ptr(beta), _ptr(pend[1]), _ptr(out), C, T, H * W, C, 1e-6,
+                                                      1 if swish else 0, _st()), f"g3_groupnorm_apply_cl_bf16({name})")
+            return out
+        stats = torch.empty((T, 2), dtype=torch.float64, device=x.device)
+        _lib.check(lib.g3_groupnorm_swish_cl_bf16(_ptr(x), C, _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(out), C, T, H * W, C, 1e-6,
+                                                  1 if swish else 0, _st()), f"g3_groupnorm_swish_cl_bf16({name})")
         return out
 
     def _resample(self, x: torch.Tensor, mode: int) -> torch.Tensor:
@@ -199,11 +215,11 @@ class CausalVideoTokenizerNet(torch.nn.Module):
     def _res_block(self, x: torch.Tensor, name: str) -> torch.Tensor:
         h = self._gn(x, f"{name}.norm1", True)
         h = self._conv(h, f"{name}.conv1.0", "s3")
-        h = self._conv(h, f"{name}.conv1.1", "t3")
+        h = self._conv(h, f"{name}.conv1.1", "t3", stats=True)
         h = self._gn(h, f"{name}.norm2", True)
         h = self._conv(h, f"{name}.conv2.0", "s3")
         skip = self._conv(x, f"{name}.nin_shortcut", "p1") if f"{name}.nin_shortcut.conv3d.weight" in self._w else x
-        return self._conv(h, f"{name}.conv2.1", "t3", residual=skip)
+        return self._conv(h, f"{name}.conv2.1", "t3", residual=skip, stats=True)  # next: a res block's norm1 / an attention norm / norm_out
 
     def _spatial_attn(self, x: torch.Tensor, name: str) -> torch.Tensor:
         T, H, W, C = x.shape
@@ -222,7 +238,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
             _lib.check(lib.g3_softmax_rows_bf16(_ptr(scores), ldp, HW, HW, float(C) ** -0.5, _st()), "g3_softmax_rows_bf16")
             _lib.check(lib.g3_transpose2d_bf16(_ptr(v[f]), C, _ptr(vT), ldp, HW, C, _st()), "g3_transpose2d_bf16")
             ops.gemm_nt(scores, vT, out=o[f])  # K = ldp (zero padded columns contribute nothing)
-        return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x)
+        return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
 
     def _temporal_attn(self, x: torch.Tensor, name: str) -> torch.Tensor:
         T, H, W, C = x.shape
@@ -233,7 +249,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         o = torch.empty_like(q)
         _lib.check(_lib.load().g3_temporal_attn_cl_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), T, H * W, C, float(C) ** -0.5, _st()),
                    "g3_temporal_attn_cl_bf16")
-        return self._conv(o, f"{name}.proj_out", "p1", residual=x)
+        return self._conv(o, f"{name}.proj_out", "p1", residual=x, stats=True)
 
     # ------------------------------------------------------------------------------------------------ networks
     @torch.no_grad()
@@ -246,7 +262,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         h = torch.empty((Tp, Hp, Wp, 192), dtype=bf16, device=vid.device)
         _lib.check(_lib.load().g3_haar3d_patch_bf16(_ptr(vid), _ptr(h), T, H, W, _st()), "g3_haar3d_patch_bf16")
         h = self._conv(h, "encoder.conv_in.0", "s3")
-        h = self._conv(h, "encoder.conv_in.1", "t3")
+        h = self._conv(h, "encoder.conv_in.1", "t3", stats=True)
         for lvl in range(3):
             for j in range(self.num_res_blocks):
                 h = self._res_block(h, f"encoder.down.{lvl}.block.{j}")
@@ -254,7 +270,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
                 d = "encoder.down.0.downsample"
                 h = self._conv(h, f"{d}.conv1", "s3s2", residual=self._resample(h, 0))
                 h = self._conv(h, f"{d}.conv2", "t3s2", residual=self._resample(h, 1))
-                h = self._conv(h, f"{d}.conv3", "p1")
+                h = self._conv(h, f"{d}.conv3", "p1", stats=True)
         h = self._res_block(h, "encoder.mid.block_1")
         h = self._spatial_attn(h, "encoder.mid.attn_1.0")
         h = self._temporal_attn(h, "encoder.mid.attn_1.1")
@@ -272,7 +288,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         h = z[0].to(bf16).permute(1, 2, 3, 0).contiguous()
         h = self._conv(h, "post_quant_conv", "p1")
         h = self._conv(h, "decoder.conv_in.0", "s3")
-        h = self._conv(h, "decoder.conv_in.1", "t3")
+        h = self._conv(h, "decoder.conv_in.1", "t3", stats=True)
         h = self._res_block(h, "decoder.mid.block_1")
         h = self._spatial_attn(h, "decoder.mid.attn_1.0")
         h = self._temporal_attn(h, "decoder.mid.attn_1.1")
@@ -286,7 +302,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
                 h = self._conv(hu, f"{u}.conv1", "t3", residual=hu)
                 hu = self._resample(h, 3)
                 h = self._conv(hu, f"{u}.conv2", "s3", residual=hu)
-                h = self._conv(h, f"{u}.conv3", "p1")
+                h = self._conv(h, f"{u}.conv3", "p1", stats=True)
         h = self._gn(h, "decoder.norm_out", True)
         h = self._conv(h, "decoder.conv_out.0", "s3")
         h = self._conv(h, "decoder.conv_out.1", "t3")

@@ -237,6 +237,18 @@ int g3_align_depth_f32(const float* source_depth, const float* target_depth, con
 int g3_conv3d_cl_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
                       int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
                       int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* stream);
+/* g3_conv3d_cl_gnstats_bf16: the same convolution, which additionally ADDS per output frame (gn_rows_per_frame = Ho*Wo consecutive output rows)
+ * the sum and sum of squares of its stored bf16 outputs to gn_stats_f64[frame][0 / 1] (doubles, zeroed by the caller) - in the kernel's epilogue
+ * where the one-wave-per-SIMD convolution kernel runs, by a statistics pass otherwise. g3_groupnorm_stats_cl_bf16 / g3_groupnorm_apply_cl_bf16
+ * are the two halves of g3_groupnorm_swish_cl_bf16: statistics (added to a zeroed buffer), and the normalisation given finished statistics
+ * - CausalNormalize of a tensor whose producing convolution already delivered them reads the tensor once instead of twice. */
+int g3_conv3d_cl_gnstats_bf16(const void* in, int64_t ld_in, const void* w, int64_t ldw, const void* bias, const void* residual,
+                              int64_t ldr, void* out, int64_t ld_out, int K, int N, int Ti, int Hi, int Wi, int To, int Ho, int Wo,
+                              int kt, int kh, int kw, int st, int sh, int sw, int ot, int oh, int ow, void* gn_stats_f64,
+                              int gn_rows_per_frame, void* stream);
+int g3_groupnorm_stats_cl_bf16(const void* x, int64_t ld, void* stats_f64, int frames, int rows_per_frame, int C, void* stream);
+int g3_groupnorm_apply_cl_bf16(const void* x, int64_t ld, const void* gamma, const void* beta, const void* stats_f64, void* out,
+                               int64_t ldo, int frames, int rows_per_frame, int C, float eps, int swish, void* stream);
 int g3_groupnorm_swish_cl_bf16(const void* x, int64_t ld, const void* gamma, const void* beta, void* stats_f64, void* out,
                                int64_t ldo, int frames, int rows_per_frame, int C, float eps, int swish, void* stream);
 int g3_haar3d_patch_bf16(const void* video, void* out, int T, int H, int W, void* stream);

@@ -200,3 +200,51 @@ def test_softmax_rows_both_paths(rows, n, ld):
     torch.cuda.synchronize()
     assert torch.equal(y[:, n:], x[:, n:])  # padding columns untouched
     assert _rel(y[:, :n], ref) < 4e-3 and float((y[:, :n].float().sum(-1) - 1).abs().max()) < 2e-2
+
+
+_CONV_GEOMS = {  # kt, kh, kw, st, sh, sw, ot, oh, ow (gen3c_amd/tokenizer.py: _GEOM)
+    "s3": (1, 3, 3, 1, 1, 1, 0, -1, -1), "t3": (3, 1, 1, 1, 1, 1, -2, 0, 0), "p1": (1, 1, 1, 1, 1, 1, 0, 0, 0),
+    "s3s2": (1, 3, 3, 1, 2, 2, 0, 0, 0), "t3s2": (3, 1, 1, 2, 1, 1, -2, 0, 0),
+}
+
+
+@pytest.mark.parametrize("kind,K,N,T,H,W", [("s3", 256, 256, 3, 24, 40), ("t3", 256, 256, 5, 16, 24), ("p1", 128, 512, 2, 17, 23), ("s3", 64, 128, 2, 9, 31),
+                                             ("s3s2", 128, 256, 2, 23, 37), ("t3s2", 192, 192, 7, 8, 16), ("t3", 512, 512, 4, 8, 20), ("s3", 192, 128, 1, 40, 64)])
+@pytest.mark.parametrize("res", [False, True])
+def test_conv_one_wave_kernel_bitwise_equals_pingpong_and_delivers_groupnorm_statistics(kind, K, N, T, H, W, res):
+    """gemm_w4_conv.hpp (one wave per SIMD, gathered token rows by per-lane address) against the 8-wave ping-pong implicit GEMM it replaces:
+    same accumulation order over (tap, channel) => BITWISE equal outputs, on every tokenizer geometry incl. borders (zero page), the causal
+    front replication, strides, ragged M / N tiles; and the GroupNorm statistics delivered by its epilogue against fp64 sums of the output."""
+    from gen3c_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    kt, kh, kw, st, sh, sw, ot, oh, ow = _CONV_GEOMS[kind]
+    To, Ho, Wo = T, H, W
+    if kind == "s3s2":
+        Ho, Wo = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+    elif kind == "t3s2":
+        To = (T + 2 - 3) // 2 + 1
+    g = torch.Generator(device=dev).manual_seed(K + N + T)
+    x = torch.randn(T, H, W, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(kt * kh * kw, N, K, device=dev, generator=g) / (K * kt * kh * kw) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+    r = torch.randn(To, Ho, Wo, N, device=dev, generator=g).to(torch.bfloat16) if res else None
+    outs = {}
+    for w4 in (1, 0):
+        ops.set_option("conv_w4", w4)
+        o = torch.full((To, Ho, Wo, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        stats = torch.zeros(To, 2, device=dev, dtype=torch.float64)
+        rc = lib.g3_conv3d_cl_gnstats_bf16(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), r.data_ptr() if res else None, N, o.data_ptr(), N, K, N, T, H, W,
+                                           To, Ho, Wo, kt, kh, kw, st, sh, sw, ot, oh, ow, stats.data_ptr(), Ho * Wo, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "g3_conv3d_cl_gnstats_bf16")
+        torch.cuda.synchronize()
+        outs[w4] = (o, stats)
+    ops.set_option("conv_w4", 1)
+    assert torch.isfinite(outs[1][0].float()).all()
+    assert torch.equal(outs[1][0], outs[0][0]), f"one-wave conv != ping-pong conv on {(outs[1][0] != outs[0][0]).sum().item()} elements"
+    of = outs[1][0].double().reshape(To, -1)
+    ref = torch.stack([of.sum(1), (of * of).sum(1)], dim=1)
+    for w4 in (1, 0):
+        st_ = outs[w4][1]
+        err = ((st_ - ref).abs() / (ref.abs() + 1.0)).max().item()
+        assert err < 2e-6, f"conv_w4={w4}: GroupNorm statistics off by {err:.2e}"

@@ -112,9 +112,9 @@ def audit_gemm_w4(asm_text: str):
     findings, cur, body = [], None, []
     funcs = {}
     for ln in asm_text.split("\n"):
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4(_conv)?_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
         if m:
-            cur = f"gemm_w4<{m.group(2)}>"
+            cur = f"gemm_w4{m.group(2) or ''}<{m.group(3)}>"
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(ln)

@@ -34,7 +34,7 @@ def main():
             return out
         return wrapper
 
-    def conv_label(out, xin, name, kind, residual=None):
+    def conv_label(out, xin, name, kind, residual=None, stats=False):
         taps = _GEOM[kind][0] * _GEOM[kind][1] * _GEOM[kind][2]
         M, N, K = out.numel() // out.shape[-1], out.shape[-1], xin.shape[-1]
         return ("conv", kind + ("+res" if residual is not None else ""), M, N, K * taps, 2.0 * M * N * K * taps,
