@@ -22,6 +22,8 @@ from . import _lib, ops
 bf16 = torch.bfloat16
 # 0: GroupNorm statistics always by their own pass over the tensor (A/B switch; default: produced in the epilogue of the convolution that writes it)
 _FUSE_GN_STATS = os.environ.get("G3_FUSE_GN_STATS", "1") != "0"
+# streams the spatial attention's frames are spread over (1 = all on the caller's stream)
+_ATTN_STREAMS = max(1, int(os.environ.get("G3_TOK_ATTN_STREAMS", "2")))  # measured 1: 47.0 / 73.0 ms, 2: 45.0 / 70.4, 3: 45.0 / 70.7, 4: 45.4 / 71.3, 6: 45.8 / 71.1 (encode / decode, one run)
 
 
 def _st() -> int:
@@ -230,15 +232,36 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         v = self._conv(hn, f"{name}.v", "p1").view(T, HW, C)
         o = torch.empty((T, HW, C), dtype=bf16, device=x.device)
         ldp = ops.ceil_to(HW, 8)
-        scores = torch.zeros((HW, ldp), dtype=bf16, device=x.device)
-        vT = torch.zeros((C, ldp), dtype=bf16, device=x.device)
         lib = _lib.load()
-        for f in range(T):  # frames are independent (time2batch, layers3d.py:362-364); one score buffer is reused
-            ops.gemm_nt(q[f], k[f], out=scores[:, :HW])
-            _lib.check(lib.g3_softmax_rows_bf16(_ptr(scores), ldp, HW, HW, float(C) ** -0.5, _st()), "g3_softmax_rows_bf16")
-            _lib.check(lib.g3_transpose2d_bf16(_ptr(v[f]), C, _ptr(vT), ldp, HW, C, _st()), "g3_transpose2d_bf16")
-            ops.gemm_nt(scores, vT, out=o[f])  # K = ldp (zero padded columns contribute nothing)
+        # Frames are independent (time2batch, layers3d.py:362-364). One frame's products do not fill the chip - scores = q k^T is 8 K tiles per
+        # 256 x 256 output tile (its launches wait on their stores), p v has (HW / 256) x 2 = 110 tiles for 256 CUs at 704 x 1280 - so the
+        # frames go round-robin over a few streams, each with its own score / V^T buffers: the tiles of one frame's launch fill the CUs another
+        # frame's leaves idle (measured: profiles/r3_*_tokenizer_breakdown.txt).
+        ns = min(_ATTN_STREAMS, T) if x.is_cuda else 1
+        main = torch.cuda.current_stream(x.device)
+        streams = [main] + [self._side_stream(i, x.device) for i in range(ns - 1)]
+        bufs = [(torch.zeros((HW, ldp), dtype=bf16, device=x.device), torch.zeros((C, ldp), dtype=bf16, device=x.device)) for _ in range(ns)]
+        ready = main.record_event()  # q, k, v, o and the zeroed buffers exist
+        for f in range(T):
+            st = streams[f % ns]
+            scores, vT = bufs[f % ns]
+            with torch.cuda.stream(st):
+                if f < ns and st is not main:
+                    st.wait_event(ready)
+                ops.gemm_nt(q[f], k[f], out=scores[:, :HW])
+                _lib.check(lib.g3_softmax_rows_bf16(_ptr(scores), ldp, HW, HW, float(C) ** -0.5, _st()), "g3_softmax_rows_bf16")
+                _lib.check(lib.g3_transpose2d_bf16(_ptr(v[f]), C, _ptr(vT), ldp, HW, C, _st()), "g3_transpose2d_bf16")
+                ops.gemm_nt(scores, vT, out=o[f])  # K = ldp (zero padded columns contribute nothing)
+        for st in streams[1:]:
+            main.wait_stream(st)  # the projection below (and the release of the buffers) follows every frame
         return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
+
+    def _side_stream(self, i: int, device) -> "torch.cuda.Stream":
+        pool = self.__dict__.setdefault("_streams", {})
+        key = (i, str(device))
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(device=device)
+        return pool[key]
 
     def _temporal_attn(self, x: torch.Tensor, name: str) -> torch.Tensor:
         T, H, W, C = x.shape

@@ -1,5 +1,5 @@
 """A few launches of the two MFMA kernels at the benchmark shapes, for rocprofv3 --pmc passes.
-(full-size self-attention: S=56320, 32 heads; the four block GEMMs)"""
+(full-size self-attention as bench.py launches it: S=56320, 32 heads, B=2, strided q / k views; the block GEMMs)"""
 import sys
 from pathlib import Path
 
@@ -9,16 +9,15 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from gen3c_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-S, H = 56320, 32
-q = torch.randn(S, H * 128, device=dev).to(torch.bfloat16)
-k = torch.randn(S, H * 128, device=dev).to(torch.bfloat16)
-v = torch.randn(S, H * 128, device=dev).to(torch.bfloat16)
-vt = ops.transpose_v(v, S, 1, H)
-out = torch.empty_like(q)
+S, H, B = 56320, 32, 2  # the benchmark's launch: conditional + unconditional branch as one B = 2 problem, q / k column views of the fused QKV buffer
+qkv = torch.randn(S * B, 3 * H * 128, device=dev).to(torch.bfloat16)
+q, k = qkv[:, :H * 128], qkv[:, H * 128:2 * H * 128]
+vt = ops.transpose_v(qkv[:, 2 * H * 128:], S, B, H)
+out = torch.empty(S * B, H * 128, device=dev, dtype=torch.bfloat16)
 for _ in range(2):
-    ops.flash_attn(q, k, vt, S, S, 1, H, out=out)
+    ops.flash_attn(q, k, vt, S, S, B, H, out=out)
 torch.cuda.synchronize()
-del q, k, v, vt, out
+del q, k, qkv, vt, out
 for (M, N, K, epi) in [(56320, 12288, 4096, 0), (56320, 16384, 4096, 1), (56320, 4096, 16384, 2)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
