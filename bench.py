@@ -39,7 +39,7 @@ def dit_forward_flops(N, D=4096, M=512, Dctx=1024, L=28, patch_dim=328, out_dim=
     return L * (28 * N * D * D + 4 * N * N * D + 4 * N * M * D + 4 * M * Dctx * D) + 2 * N * patch_dim * D + 2 * N * D * out_dim
 
 
-def cpu_baseline(threads: int):
+def cpu_baseline(threads: int, blocks: int = 1):
     """Oracle ('port') timed on the host cores on a bounded sample of BASELINE.json's configs[0] shape: ONE Cosmos-7B-width block
     (D=4096, 32 heads, MLP 16384, context 512x1024) of a DiT forward on the 16x64x64 latent = 16 384 tokens, fp32, once. Measured: that
     block (incl. patch embedding / final layer). Extrapolated by FLOPs: the other 27 blocks, the second forward of the step and the
@@ -57,15 +57,16 @@ def cpu_baseline(threads: int):
         sd[f"extra_pos_embedder.pos_emb_{a}"] = W(n, D)
     sd["t_embedder.1.linear_1.weight"] = W(D, D)
     sd["t_embedder.1.linear_2.weight"] = W(3 * D, D)
-    pre = "blocks.block0.blocks"
-    for j, cd in ((0, D), (1, 1024)):
-        a = f"{pre}.{j}.block.attn"
-        sd[f"{a}.to_q.0.weight"] = W(D, D); sd[f"{a}.to_q.1.weight"] = torch.ones(128)
-        sd[f"{a}.to_k.0.weight"] = W(D, cd); sd[f"{a}.to_k.1.weight"] = torch.ones(128)
-        sd[f"{a}.to_v.0.weight"] = W(D, cd); sd[f"{a}.to_out.0.weight"] = W(D, D)
-    sd[f"{pre}.2.block.layer1.weight"] = W(4 * D, D); sd[f"{pre}.2.block.layer2.weight"] = W(D, 4 * D)
-    for j in range(3):
-        sd[f"{pre}.{j}.adaLN_modulation.1.weight"] = W(256, D); sd[f"{pre}.{j}.adaLN_modulation.2.weight"] = W(3 * D, 256)
+    for bi in range(blocks):
+        pre = f"blocks.block{bi}.blocks"
+        for j, cd in ((0, D), (1, 1024)):
+            a = f"{pre}.{j}.block.attn"
+            sd[f"{a}.to_q.0.weight"] = W(D, D); sd[f"{a}.to_q.1.weight"] = torch.ones(128)
+            sd[f"{a}.to_k.0.weight"] = W(D, cd); sd[f"{a}.to_k.1.weight"] = torch.ones(128)
+            sd[f"{a}.to_v.0.weight"] = W(D, cd); sd[f"{a}.to_out.0.weight"] = W(D, D)
+        sd[f"{pre}.2.block.layer1.weight"] = W(4 * D, D); sd[f"{pre}.2.block.layer2.weight"] = W(D, 4 * D)
+        for j in range(3):
+            sd[f"{pre}.{j}.adaLN_modulation.1.weight"] = W(256, D); sd[f"{pre}.{j}.adaLN_modulation.2.weight"] = W(3 * D, 256)
     sd["final_layer.linear.weight"] = W(64, D)
     sd["final_layer.adaLN_modulation.1.weight"] = W(256, D); sd["final_layer.adaLN_modulation.2.weight"] = W(2 * D, 256)
     sd["affline_norm.weight"] = torch.ones(D)
@@ -79,14 +80,16 @@ def cpu_baseline(threads: int):
     with torch.no_grad():
         for _ in range(reps):
             dit_oracle.dit_forward(sd, x, torch.tensor([0.3]), ctx, mask, pose, torch.zeros(1, 1, 8 * Hh, 8 * Ww),
-                                   torch.tensor([24.0]), num_blocks=1, num_heads=H)
+                                   torch.tensor([24.0]), num_blocks=blocks, num_heads=H)
     dt = time.perf_counter() - t0
-    flops = reps * dit_forward_flops(N, L=1)
+    flops = reps * dit_forward_flops(N, L=blocks)
     rate = flops / dt
     step_flops = 2 * dit_forward_flops(56320)
     return dict(value=rate / step_flops, unit="denoise-steps/sec", cores=threads, kind="port",
-                sample=f"oracle/dit_oracle.py fp32: 1 of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, measured "
-                       f"{dt:.1f}s = {rate/1e12:.3f} TFLOP/s; extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step)")
+                seconds=round(dt, 2), blocks=blocks,
+                sample=f"oracle/dit_oracle.py fp32: {blocks} of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, measured "
+                       f"{dt:.1f}s = {rate/1e12:.3f} TFLOP/s; extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step); "
+                       f"per-block linearity of the extrapolation checked once: profiles/r3_cpu_baseline_linearity.txt")
 
 
 def stage_rooflines(dev):

@@ -407,6 +407,64 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const bf16_t* __rest
     }
 }
 
+// Same attention, one wave per PIXEL: the pixel's T <= 16 key and value rows are read once into registers (a lane holds 8 of the C <= 512
+// channels of every frame) and serve all T query frames; the first form reads them once per query frame (8.5 x the bytes at T = 16, through
+// L2). Same operation order per output as temporal_attn_kernel => bitwise equal results (tested).
+template <int TMAX>
+__global__ __launch_bounds__(256) void temporal_attn_px_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                               const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int T, int HW,
+                                                               int C, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= HW) return;
+    const int c = lane * 8;
+    const bool act = c < C;
+    bf16x8 rk[TMAX], rv[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const bool ok = act && t < T;
+        rk[t] = ok ? load_bf16x8(k + ((int64_t)t * HW + pix) * C + c) : zero_bf16x8();
+        rv[t] = ok ? load_bf16x8(v + ((int64_t)t * HW + pix) * C + c) : zero_bf16x8();
+    }
+    bf16x8 rq = act ? load_bf16x8(q + pix * C + c) : zero_bf16x8();
+    static_for<0, TMAX>([&](auto tic) {
+        constexpr int ti = decltype(tic)::value;
+        if (ti >= T) return;  // wave-uniform
+        const bf16x8 qn = (act && ti + 1 < T) ? load_bf16x8(q + ((int64_t)(ti + 1) * HW + pix) * C + c) : zero_bf16x8();  // next query row in flight
+        float sc[ti + 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)rq[e] * (float)rk[tj][e];
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) part += __shfl_xor(part, s2, 64);
+            part = (float)f32_to_bf16(part) * scale;  // bmm output is bf16 in the reference
+            sc[tj] = part;
+            mx = fmaxf(mx, part);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) { sc[tj] = __expf(sc[tj] - mx); den += sc[tj]; }
+        const float inv = 1.0f / den;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            const float p = (float)f32_to_bf16(sc[tj] * inv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * (float)rv[tj][e];
+        }
+        if (act) {
+            bf16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = f32_to_bf16(acc[e]);
+            store_bf16x8(o + ((int64_t)ti * HW + pix) * C + c, r);
+        }
+        rq = qn;
+    });
+}
+
 int grid1d(int64_t work) {
     int64_t g = (work + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -512,6 +570,11 @@ extern "C" int g3_temporal_attn_cl_bf16(const void* q, const void* k, const void
                                         void* stream) {
     if (!q || !k || !v || !o) return g3_set_error(G3_ERR_ARG, "g3_temporal_attn_cl_bf16: null operand");
     if (T <= 0 || T > 64 || HW <= 0 || C <= 0 || (C & 7)) return g3_set_error(G3_ERR_ARG, "g3_temporal_attn_cl_bf16: need T <= 64 and C %% 8 == 0");
+    if (g3_opt_tok_tattn_px && C <= 512 && T <= 16 && !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) {
+        hipLaunchKernelGGL(temporal_attn_px_kernel<16>, dim3((unsigned)((HW + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, T, HW, C, scale);
+        return g3_check_launch("g3_temporal_attn_cl_bf16");
+    }
     const int64_t waves = (int64_t)HW * T;
     hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, T, HW, C, scale);

@@ -248,3 +248,29 @@ def test_conv_one_wave_kernel_bitwise_equals_pingpong_and_delivers_groupnorm_sta
         st_ = outs[w4][1]
         err = ((st_ - ref).abs() / (ref.abs() + 1.0)).max().item()
         assert err < 2e-6, f"conv_w4={w4}: GroupNorm statistics off by {err:.2e}"
+
+
+@pytest.mark.parametrize("T,HW,C", [(16, 1000, 512), (3, 77, 64), (5, 256, 256), (1, 40, 128)])
+def test_temporal_attention_per_pixel_kernel_bitwise_equals_first_form_and_matches_fp32(T, HW, C):
+    """CausalTemporalAttnBlock core (layers3d.py:386-427): the one-wave-per-pixel kernel (K / V rows of a pixel read once for all query frames)
+    against the one-wave-per-(pixel, query frame) kernel - same operation order => bitwise - and against an fp32 causal softmax."""
+    from gen3c_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(T * 7 + C)
+    q, k, v = (torch.randn(T, HW, C, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+    outs = []
+    for px in (1, 0):
+        ops.set_option("tok_tattn_px", px)
+        o = torch.empty_like(q)
+        _lib.check(lib.g3_temporal_attn_cl_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), T, HW, C, float(C) ** -0.5,
+                                                torch.cuda.current_stream().cuda_stream), "g3_temporal_attn_cl_bf16")
+        outs.append(o)
+    ops.set_option("tok_tattn_px", 1)
+    assert torch.equal(outs[0], outs[1])
+    qf, kf, vf = (t.float().permute(1, 0, 2) for t in (q, k, v))  # [HW, T, C]
+    sc = (qf @ kf.transpose(1, 2)) * float(C) ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(T, T, device=dev, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ vf).permute(1, 0, 2)
+    r = _rel(outs[0], ref)
+    assert r < 8e-3, f"rel-L2 {r:.3e} vs fp32 causal softmax"
