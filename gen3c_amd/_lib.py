@@ -47,6 +47,9 @@ SIGNATURES = {
     "g3_warp_resolve_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "g3_warp_windows_workspace_bytes": [i32, i32, i32],
     "g3_warp_splat_resolve_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "g3_render_workspace_bytes": [i32, i32, i32, i32],
+    "g3_render_workspace_init": [vp, i32, i32, i32, i32, vp],
+    "g3_render_items_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "g3_mesh_occlusion_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "g3_unproject_points_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "g3_dit_patchify_bf16": [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -70,7 +73,7 @@ SIGNATURES = {
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }
 _RESTYPES = {"g3_last_error": C.c_char_p, "g3_flash_attn_kernel_name": C.c_char_p, "g3_gemm_kernel_name": C.c_char_p, "g3_flash_attn_kernel_name_ex": C.c_char_p, "g3_align_depth_workspace_bytes": C.c_size_t,
-             "g3_warp_windows_workspace_bytes": C.c_size_t}
+             "g3_warp_windows_workspace_bytes": C.c_size_t, "g3_render_workspace_bytes": C.c_size_t}
 
 
 class Gen3cHipError(RuntimeError):

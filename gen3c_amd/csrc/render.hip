@@ -21,6 +21,7 @@
 // -ffp-contract=off): pixel indices and masks are bit-exact w.r.t. the oracle; accumulated floats depend on atomic
 // order (as they do in the reference) and on libm's log1p/exp.
 #include "common.hpp"
+#include <mutex>
 
 namespace {
 
@@ -36,15 +37,17 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const float* __restri
                                                            float* __restrict__ zbuf, float* __restrict__ flow,
                                                            float* __restrict__ cam_out, float* __restrict__ maskz,
                                                            unsigned* __restrict__ group_max, int n, int h, int w,
-                                                           int group_size) {
+                                                           int group_size, const int* __restrict__ src = nullptr) {
     const int item = blockIdx.y;
     const int hw = h * w;
+    const int sitem = src ? src[item] : item;  // cache entry (source view) this item renders: points / mask1 are per SOURCE when src is given
     const float* W = w2c + item * 16;
     const float* K = Kmat + item * 9;
     float local_max = 0.f;  // log1p(max(z,0)) >= 0
     for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += gridDim.x * 256) {
         const int64_t o = (int64_t)item * hw + pix;
-        const float x = points[o * 3 + 0], y = points[o * 3 + 1], zz = points[o * 3 + 2];
+        const int64_t so = (int64_t)sitem * hw + pix;
+        const float x = points[so * 3 + 0], y = points[so * 3 + 1], zz = points[so * 3 + 2];
         float cam[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const float* __restri
         flow[((int64_t)item * 2 + 0) * hw + pix] = u - (float)px;
         flow[((int64_t)item * 2 + 1) * hw + pix] = v - (float)py;
         zbuf[o] = z;
-        const float m = (mask1 ? mask1[o] : 1.0f) * ((z > 0.f) ? 1.0f : 0.0f);
+        const float m = (mask1 ? mask1[so] : 1.0f) * ((z > 0.f) ? 1.0f : 0.0f);
         maskz[o] = m;
         if (cam_out) { cam_out[o * 3 + 0] = cam[0]; cam_out[o * 3 + 1] = cam[1]; cam_out[o * 3 + 2] = cam[2]; }
         local_max = fmaxf(local_max, log1pf(fmaxf(z, 0.f)));  // NaN z is ignored by fmaxf, as by torch.max? (see header note)
@@ -273,12 +276,14 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                                                                  const float* __restrict__ flow, const float* __restrict__ maskz,
                                                                  const unsigned* __restrict__ group_max, float* __restrict__ accum,
                                                                  float* __restrict__ windows, int* __restrict__ origins, int n, int h, int w,
-                                                                 int group_size, int tiles_x) {
+                                                                 int group_size, int tiles_x, const int* __restrict__ src_idx = nullptr,
+                                                                 unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
     __shared__ int org[2];
     __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
     const int item = blockIdx.y;
     const int hw = h * w;
+    const int sitem = src_idx ? src_idx[item] : item;  // the image is per SOURCE view when src_idx is given
     const float lmax = __uint_as_float(group_max[item / group_size]);
     const int aw = w + 2;
     float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
@@ -309,9 +314,9 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         const float expo = logd / (lmax + 1e-7f) * 50.0f;
         const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
         wscale[k] = dw;
-        col[k][0] = image[((int64_t)item * 3 + 0) * hw + pix];
-        col[k][1] = image[((int64_t)item * 3 + 1) * hw + pix];
-        col[k][2] = image[((int64_t)item * 3 + 2) * hw + pix];
+        col[k][0] = image[((int64_t)sitem * 3 + 0) * hw + pix];
+        col[k][1] = image[((int64_t)sitem * 3 + 1) * hw + pix];
+        col[k][2] = image[((int64_t)sitem * 3 + 2) * hw + pix];
         col[k][3] = z;
         mnx = min(mnx, g[k].fx);
         mny = min(mny, g[k].fy);
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
             float* a = acc_item + ((int64_t)y * aw + x) * ACC_C;
 #pragma unroll
             for (int e = 0; e < ACC_C; ++e) unsafeAtomicAdd(a + e, v[e]);
+            if (dirty) dirty[item] = epoch;  // this launch put something into the item's dense accumulator: the gather must read (and clear) it
         }
     };
 #pragma unroll
@@ -447,16 +453,21 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* __restrict__ windows, const int* __restrict__ origins,
-                                                                  const float* __restrict__ accum, float* __restrict__ frame,
+                                                                  float* __restrict__ accum, float* __restrict__ frame,
                                                                   float* __restrict__ mask, float* __restrict__ depth, int n, int h, int w,
-                                                                  int ntiles, int tiles_x) {
+                                                                  int ntiles, int tiles_x, const unsigned* __restrict__ dirty = nullptr,
+                                                                  unsigned epoch = 0) {
     __shared__ int lst[256 * 3];  // overlapping source tiles of one scan chunk: tile, ox, oy
     __shared__ int wave_cnt[4];
     const int item = blockIdx.y;
     const int hw = h * w;
     const int aw = w + 2;
     const int dy0 = (blockIdx.x / tiles_x) * TS, dx0 = (blockIdx.x % tiles_x) * TS;  // output pixel (py, px) = accumulator texel (py + 1, px + 1)
-    const float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
+    float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
+    // dirty == nullptr: the caller zeroed the accumulator before the splat and it is read unconditionally (g3_warp_splat_resolve_f32).
+    // Otherwise (g3_render_items_f32) the accumulator is all zero except for items the splat kernel stamped with this launch's epoch: only those
+    // read it (20 bytes per pixel saved on the common path) and put the zeros back, so the buffer never needs a clearing pass.
+    const bool read_acc = dirty == nullptr || dirty[item] == epoch;
     const int* org_item = origins + (int64_t)item * ntiles * 2;
     const float* win_item = windows + (int64_t)item * ntiles * (WIN * WIN * ACC_C);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -470,9 +481,17 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
         inb[k] = py < h && px < w;
         gy[k] = py + 1;
         gx[k] = px + 1;
-        const float* a = acc_item + ((int64_t)gy[k] * aw + gx[k]) * ACC_C;
+        float* a = acc_item + ((int64_t)gy[k] * aw + gx[k]) * ACC_C;
+        bool any = false;
 #pragma unroll
-        for (int e = 0; e < ACC_C; ++e) sum[k][e] = inb[k] ? a[e] : 0.f;
+        for (int e = 0; e < ACC_C; ++e) {
+            sum[k][e] = (inb[k] && read_acc) ? a[e] : 0.f;
+            any = any || sum[k][e] != 0.f;
+        }
+        if (dirty != nullptr && any) {
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) a[e] = 0.f;
+        }
     }
     for (int base = 0; base < ntiles; base += 256) {
         const int t = base + threadIdx.x;
@@ -568,8 +587,9 @@ G3_DEVICE void bilinear_src(int i, float scale, int n_in, int& i0, int& i1, floa
 
 __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __restrict__ cam, const uint8_t* __restrict__ bmask,
                                                               float* __restrict__ pts, uint8_t* __restrict__ m, int n, int h,
-                                                              int w, int nh, int nw) {
+                                                              int w, int nh, int nw, const int* __restrict__ src = nullptr) {
     const int item = blockIdx.y;
+    const int sitem = src ? src[item] : item;
     const float sy = (float)h / (float)nh, sx = (float)w / (float)nw;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nh * nw; idx += gridDim.x * 256) {
         const int i = idx / nw, j = idx - i * nw;
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __res
             pts[((int64_t)item * nh * nw + idx) * 3 + k] = top * wy0 + bot * wy1;
         }
         const int my = (int)floorf((float)i * sy), mx = (int)floorf((float)j * sx);
-        m[(int64_t)item * nh * nw + idx] = bmask[(int64_t)item * h * w + (int64_t)my * w + mx] ? 1 : 0;
+        m[(int64_t)item * nh * nw + idx] = bmask[(int64_t)sitem * h * w + (int64_t)my * w + mx] ? 1 : 0;
     }
 }
 
@@ -804,7 +824,7 @@ extern "C" int g3_warp_splat_resolve_f32(const float* image, const float* z, con
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image, z, flow, maskz, (const unsigned*)group_max, accum,
                        windows, origins, n, h, w, group_size, tiles_x);
-    hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, (const float*)accum,
+    hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum,
                        frame, mask, depth, n, h, w, ntiles, tiles_x);
     return g3_check_launch("g3_warp_splat_resolve_f32");
 }
@@ -840,4 +860,107 @@ extern "C" int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int 
     if (n <= 0 || h <= 0 || w <= 0 || window <= 0 || (window & 1) == 0) return g3_set_error(G3_ERR_ARG, "g3_reliable_depth_mask_f32: window must be odd");
     hipLaunchKernelGGL(reliable_mask_kernel, dim3(grid_x(h * w), n), dim3(256), 0, (hipStream_t)stream, depth, out, n, h, w, window, ratio_thresh, eps);
     return g3_check_launch("g3_reliable_depth_mask_f32");
+}
+
+/* ---- one call per batch of render items ---------------------------------------------------------------------------------------------------
+ * Cache3D_Base.render_cache (cache_3d.py:151-236) renders n = (target frame, cache buffer) items from n_src cached source views; the reference
+ * expands the sources to one copy per item and loops forward_warp over pairs. Here an item names its source (src_index), so nothing is
+ * replicated, and project -> window splat -> gather / resolve -> (mesh occlusion) run back to back on one workspace. */
+namespace {
+struct RenderWs {
+    size_t z, flow, maskz, cam, gmax, accum, windows, origins, dirty, pts_ds, m_ds, tmin, total;
+};
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
+    RenderWs L;
+    const size_t hw = (size_t)h * w;
+    const size_t ntiles = (size_t)((w + TS - 1) / TS) * ((h + TS - 1) / TS);
+    const size_t nh = h / factor, nw = w / factor;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = align256(o + bytes); return at; };
+    L.accum = take((size_t)n * (h + 2) * (w + 2) * ACC_C * sizeof(float));  // first: the part g3_render_workspace_init has to zero
+    L.dirty = take((size_t)n * sizeof(unsigned));
+    L.z = take(n * hw * sizeof(float));
+    L.flow = take(n * hw * 2 * sizeof(float));
+    L.maskz = take(n * hw * sizeof(float));
+    L.cam = take(n * hw * 3 * sizeof(float));
+    L.gmax = take(((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned));
+    L.windows = take((size_t)n * ntiles * WIN * WIN * ACC_C * sizeof(float));
+    L.origins = take((size_t)n * ntiles * 2 * sizeof(int));
+    L.pts_ds = take((size_t)n * nh * nw * 3 * sizeof(float));
+    L.m_ds = take((size_t)n * nh * nw);
+    L.tmin = take(n * hw * sizeof(unsigned));
+    L.total = o;
+    return L;
+}
+unsigned g_render_epoch = 0;  // stamps the items whose dense accumulator a launch touched; any value that differs from earlier launches' works
+std::mutex g_render_epoch_mu;
+}  // namespace
+
+extern "C" size_t g3_render_workspace_bytes(int n, int h, int w, int group_size) {
+    if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return 0;
+    return render_ws_layout(n, h, w, group_size, 4).total;
+}
+
+extern "C" int g3_render_workspace_init(void* workspace, int n, int h, int w, int group_size, void* stream) {
+    if (!workspace || ((uintptr_t)workspace & 255)) return g3_set_error(G3_ERR_ARG, "g3_render_workspace_init: workspace must be 256-byte aligned");
+    if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_render_workspace_init: bad shape");
+    const RenderWs L = render_ws_layout(n, h, w, group_size, 4);
+    hipError_t e = hipMemsetAsync((char*)workspace + L.accum, 0, L.z - L.accum, (hipStream_t)stream);  // accumulators + dirty stamps
+    if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_workspace_init: memset: %s", hipGetErrorString(e));
+    return G3_OK;
+}
+
+extern "C" int g3_render_items_f32(const float* points_src, const float* image_src, const float* mask_src, const uint8_t* boundary_src,
+                                   const int* src_index, const float* w2c, const float* K, const float* Kinv, void* workspace, float* frame,
+                                   float* mask, float* depth, float* flow_out, int n, int n_src, int h, int w, int group_size, void* stream) {
+    if (!points_src || !image_src || !src_index || !w2c || !K || !workspace || !frame || !mask)
+        return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: null operand");
+    if (n <= 0 || n_src <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: bad shape");
+    if ((uintptr_t)workspace & 255) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: workspace must be 256-byte aligned");
+    if (boundary_src && (!Kinv || !depth)) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: foreground masking needs Kinv and a depth output");
+    const int factor = 4;  // mesh_downsample_factor (forward_warp_utils_pytorch.py:290)
+    if (boundary_src && (h / factor < 2 || w / factor < 2)) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: frame too small for the occlusion mesh");
+    const RenderWs L = render_ws_layout(n, h, w, group_size, factor);
+    char* ws = (char*)workspace;
+    float* z = (float*)(ws + L.z);
+    float* flow = flow_out ? flow_out : (float*)(ws + L.flow);
+    float* maskz = (float*)(ws + L.maskz);
+    float* cam = boundary_src ? (float*)(ws + L.cam) : nullptr;
+    unsigned* gmax = (unsigned*)(ws + L.gmax);
+    float* accum = (float*)(ws + L.accum);
+    float* windows = (float*)(ws + L.windows);
+    int* origins = (int*)(ws + L.origins);
+    unsigned* dirty = (unsigned*)(ws + L.dirty);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned epoch;
+    {
+        std::lock_guard<std::mutex> lock(g_render_epoch_mu);
+        epoch = ++g_render_epoch;
+        if (epoch == 0) epoch = ++g_render_epoch;  // 0 is what g3_render_workspace_init leaves in the stamps
+    }
+    hipError_t e = hipMemsetAsync(gmax, 0, ((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned), s);
+    if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, cam, maskz, gmax,
+                       n, h, w, group_size, src_index);
+    const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
+                       (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
+    hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
+                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch);
+    if (boundary_src) {
+        const int nh = h / factor, nw = w / factor;
+        float* pts_ds = (float*)(ws + L.pts_ds);
+        uint8_t* m_ds = (uint8_t*)(ws + L.m_ds);
+        unsigned* tmin = (unsigned*)(ws + L.tmin);
+        e = hipMemsetD32Async((hipDeviceptr_t)tmin, 0x7f800000, (size_t)n * h * w, s);  // +inf bit pattern
+        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, (const float*)cam, boundary_src, pts_ds, m_ds, n, h, w, nh, nw,
+                           src_index);
+        const int npatch = (nh - 1) * (nw - 1);
+        hipLaunchKernelGGL(mesh_raster_kernel, dim3((npatch + 3) / 4, n), dim3(256), 0, s, (const float*)pts_ds, (const uint8_t*)m_ds, K, Kinv, tmin, n, h, w, nh,
+                           nw, 1e-8f);
+        hipLaunchKernelGGL(mesh_apply_kernel, dim3(grid_x(h * w), n), dim3(256), 0, s, (const unsigned*)tmin, Kinv, frame, mask, depth, n, h, w);
+    }
+    return g3_check_launch("g3_render_items_f32");
 }

@@ -69,6 +69,27 @@ def reliable_depth_mask_range_batch(depth: torch.Tensor, window_size: int = 5, r
     return out.bool().reshape(b, 1, h, w)
 
 
+_ITEMS_CALL = True   # False: Cache3D.render_cache expands the sources per item and loops forward_warp (the reference's structure; A/B and tests)
+_RENDER_WS: dict = {}
+
+
+def _render_workspace(lib, n: int, h: int, w: int, group_size: int, dev, stream) -> torch.Tensor:
+    """Workspace of g3_render_items_f32, cached per (n, h, w, group_size, device) and prepared once (g3_render_workspace_init): the kernels
+    keep its accumulator part zero themselves, so a render never clears anything. Launches are ordered on the stream."""
+    key = (n, h, w, group_size, str(dev))
+    t = _RENDER_WS.get(key)
+    if t is None:
+        nbytes = int(lib.g3_render_workspace_bytes(n, h, w, group_size))
+        t = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-t.data_ptr()) % 256
+        t = t[off:off + nbytes]
+        _lib.check(lib.g3_render_workspace_init(t.data_ptr(), n, h, w, group_size, stream), "g3_render_workspace_init")
+        while len(_RENDER_WS) >= 4:  # chunk size + a ragged tail per resolution: bounded
+            _RENDER_WS.pop(next(iter(_RENDER_WS)))
+        _RENDER_WS[key] = t
+    return t
+
+
 _WINDOW_SPLAT = True  # False: the two-call form (splat into the global accumulator with atomics, then resolve) - kept for A/B and tests
 _WS_CACHE: dict = {}
 
@@ -216,6 +237,47 @@ class Cache3D_Base:
             dm = reliable_depth_mask_range_batch(input_depth.reshape(-1, 1, H, W))
             self.boundary_mask = (~dm).reshape(B, F, N, V, 1, H, W)
 
+    def _render_items(self, target_w2cs, target_intrinsics, render_depth: bool, start_frame_idx: int, Ft: int, lo: int, hi: int, step: int):
+        """Items [lo, hi) of the flattened (B, F_t, N) axis through g3_render_items_f32 -> (frames [m,3,H,W] or None, masks [m,1,H,W],
+        depths [m,H,W] or None). Source of item (b, f, n): cache entry (b, start_frame_idx + f if the cache holds one entry per frame else 0, n)."""
+        B, F, N, V, C, H, W = self.input_image.shape
+        dev = self.device
+        m = hi - lo
+        need_depth = bool(render_depth or self.foreground_masking)
+        frames = torch.empty((m, 3, H, W), dtype=f32, device=dev)
+        masks = torch.empty((m, 1, H, W), dtype=f32, device=dev)
+        depths = torch.empty((m, H, W), dtype=f32, device=dev) if need_depth else None
+        if m == 0:
+            return (None if render_depth else frames), masks, (depths if render_depth else None)
+        Fs = self.input_image[:, start_frame_idx:start_frame_idx + Ft].shape[1]
+        assert Fs in (1, Ft), f"the cache holds {Fs} source frames for {Ft} target frames"
+        b_i = torch.arange(B, device=dev).view(B, 1, 1)
+        f_i = (torch.arange(Ft, device=dev) if Fs == Ft else torch.zeros(Ft, dtype=torch.long, device=dev)).view(1, Ft, 1) + start_frame_idx
+        n_i = torch.arange(N, device=dev).view(1, 1, N)
+        src_index = ((b_i * F + f_i) * N + n_i).reshape(-1).to(torch.int32)[lo:hi].contiguous()
+        w2cs = target_w2cs.to(dev, f32).reshape(B, Ft, 1, 16).expand(B, Ft, N, 16).reshape(-1, 16)[lo:hi].contiguous()
+        Ks = target_intrinsics.to(dev, f32).reshape(B, Ft, 1, 9).expand(B, Ft, N, 9).reshape(-1, 9)[lo:hi].contiguous()
+        n_src = B * F * N
+        img_src = self.input_image.reshape(n_src, C, H, W).contiguous()  # views when the cache tensors are contiguous (they are)
+        pts_src = self.input_points.reshape(n_src, H, W, 3).contiguous()
+        msk_src = None if self.input_mask is None else self.input_mask.reshape(n_src, H, W).contiguous()
+        bnd_src = kinv = None
+        if self.foreground_masking:
+            bm = self.boundary_mask
+            bnd_src = bm.expand(B, F, N, V, 1, H, W).reshape(n_src, H, W).to(torch.uint8).contiguous()
+            kinv = _host_inverse(Ks.reshape(-1, 3, 3)).reshape(-1, 9).contiguous()
+        lib = _lib.load()
+        st = _stream()
+        for i in range(0, m, step):
+            j = min(i + step, m)
+            ws = _render_workspace(lib, j - i, H, W, 2, dev, st)
+            _lib.check(lib.g3_render_items_f32(_p(pts_src, "points_src"), _p(img_src, "image_src"), _p(msk_src, "mask_src"), _p(bnd_src, "boundary_src", torch.uint8),
+                                               _p(src_index[i:j], "src_index", torch.int32), _p(w2cs[i:j], "w2c"), _p(Ks[i:j], "K"),
+                                               _p(kinv[i:j], "Kinv") if kinv is not None else 0, ws.data_ptr(), _p(frames[i:j], "frame"),
+                                               _p(masks[i:j], "mask"), _p(depths[i:j], "depth") if depths is not None else 0, 0, j - i, n_src, H, W, 2, st),
+                       "g3_render_items_f32")
+        return (None if render_depth else frames), masks, (depths if render_depth else None)
+
     def input_frame_count(self) -> int:
         return self.input_image.shape[1]
 
@@ -229,15 +291,7 @@ class Cache3D_Base:
         bs, Ft = target_w2cs.shape[:2]
         B, F, N, V, C, H, W = self.input_image.shape
         assert bs == B
-        sl = slice(start_frame_idx, start_frame_idx + Ft)
-        ex = lambda t, tail: t[:, sl].expand(B, Ft, N, V, *tail).reshape(B * Ft * N, *tail)
-        imgs = ex(self.input_image, (C, H, W))
-        pts = ex(self.input_points, (H, W, 3))
-        msk = None if self.input_mask is None else ex(self.input_mask, (1, H, W))
-        bnd = None if self.boundary_mask is None else self.boundary_mask.expand(B, Ft, N, V, 1, H, W).reshape(B * Ft * N, H, W)
-        w2cs = target_w2cs.to(self.device, f32).reshape(B, Ft, 1, 4, 4).expand(B, Ft, N, 4, 4).reshape(-1, 4, 4)
-        Ks = target_intrinsics.to(self.device, f32).reshape(B, Ft, 1, 3, 3).expand(B, Ft, N, 3, 3).reshape(-1, 3, 3)
-        n = imgs.shape[0]
+        n = B * Ft * N
         step = max(2, items_per_launch // 2 * 2)  # never split a reference pair
         # Multi-GPU: the items are independent EXCEPT that bilinear_splatting normalises its depth weights by the
         # maximum over the 2 items of one reference call - so the unit that is sharded over the ranks of `shard_group` is the PAIR
@@ -252,19 +306,34 @@ class Cache3D_Base:
             counts = [min(2 * b, n) - min(2 * a, n) for a, b in ranges]
             lo, hi = min(2 * ranges[rank][0], n), min(2 * ranges[rank][1], n)
         frames, masks, depths = [], [], []
-        for i in range(lo, hi, step):
-            s = slice(i, min(i + step, hi))
-            fr, mk, dp, _ = forward_warp(imgs[s], None if msk is None else msk[s], None, None, w2cs[s], Ks[s], Ks[s],
-                                         render_depth=render_depth, world_points1=pts[s],
-                                         foreground_masking=self.foreground_masking,
-                                         boundary_mask=None if bnd is None else bnd[s], group_size=2)
-            frames.append(fr)
-            masks.append(mk)
-            if render_depth:
-                depths.append(dp)
+        if _ITEMS_CALL:
+            # one C call per chunk of items (g3_render_items_f32): every item NAMES its source view instead of getting a copy of it, the outputs
+            # land in one preallocated tensor, the workspace (incl. its self-cleaning accumulator) is cached per chunk size
+            fr, mk, dp = self._render_items(target_w2cs, target_intrinsics, render_depth, start_frame_idx, Ft, lo, hi, step)
+            frames, masks, depths = [fr], [mk], [dp]
+        else:
+            sl = slice(start_frame_idx, start_frame_idx + Ft)
+            ex = lambda t, tail: t[:, sl].expand(B, Ft, N, V, *tail).reshape(B * Ft * N, *tail)
+            imgs = ex(self.input_image, (C, H, W))
+            pts = ex(self.input_points, (H, W, 3))
+            msk = None if self.input_mask is None else ex(self.input_mask, (1, H, W))
+            bnd = None if self.boundary_mask is None else self.boundary_mask.expand(B, Ft, N, V, 1, H, W).reshape(B * Ft * N, H, W)
+            w2cs = target_w2cs.to(self.device, f32).reshape(B, Ft, 1, 4, 4).expand(B, Ft, N, 4, 4).reshape(-1, 4, 4)
+            Ks = target_intrinsics.to(self.device, f32).reshape(B, Ft, 1, 3, 3).expand(B, Ft, N, 3, 3).reshape(-1, 3, 3)
+            for i in range(lo, hi, step):
+                s = slice(i, min(i + step, hi))
+                fr, mk, dp, _ = forward_warp(imgs[s], None if msk is None else msk[s], None, None, w2cs[s], Ks[s], Ks[s],
+                                             render_depth=render_depth, world_points1=pts[s],
+                                             foreground_masking=self.foreground_masking,
+                                             boundary_mask=None if bnd is None else bnd[s], group_size=2)
+                frames.append(fr)
+                masks.append(mk)
+                if render_depth:
+                    depths.append(dp)
 
         def collect(parts, tail):
-            local = torch.cat(parts) if parts else torch.empty((0, *tail), dtype=f32, device=self.device)
+            parts = [p_ for p_ in parts if p_ is not None]
+            local = (parts[0] if len(parts) == 1 else torch.cat(parts)) if parts else torch.empty((0, *tail), dtype=f32, device=self.device)
             if counts is None:
                 return local
             from .parallel import gather_rows

@@ -202,6 +202,20 @@ size_t g3_warp_windows_workspace_bytes(int n, int h, int w);
 int g3_warp_splat_resolve_f32(const float* image, const float* z, const float* flow, const float* maskz, const void* group_max,
                               float* accum, void* workspace, float* frame, float* mask, float* depth, int n, int h, int w,
                               int group_size, void* stream);
+/* One call per batch of render items (Cache3D_Base.render_cache, cache_3d.py:151-236): n items = (target camera, cached source view) pairs rendered
+ * from n_src source views WITHOUT replicating the sources - item i reads source src_index[i] (device int32 [n]): points_src [n_src][h][w][3],
+ * image_src [n_src][3][h][w], mask_src [n_src][h][w] or NULL, boundary_src u8 [n_src][h][w] or NULL (NULL = no foreground masking; else Kinv
+ * [n][9] and depth are required). w2c [n][16], K [n][9] are the TARGET cameras. Runs project -> window splat -> gather / resolve -> (mesh
+ * occlusion) as g3_warp_project_f32 + g3_warp_splat_resolve_f32 + g3_mesh_occlusion_f32 would on expanded inputs (same arithmetic, same
+ * group_size pairing). Outputs frame [n][3][h][w], mask [n][h][w], depth [n][h][w] or NULL, flow_out [n][2][h][w] or NULL.
+ * workspace: g3_render_workspace_bytes(n, h, w, group_size) bytes, 256-byte aligned, prepared ONCE by g3_render_workspace_init for exactly this
+ * (n, h, w, group_size) and then reused call after call: the dense out-of-window accumulator inside it is kept all-zero by the kernels
+ * themselves (items whose accumulator a launch touched are stamped, and only those are read back and cleared), so no per-call clearing pass. */
+size_t g3_render_workspace_bytes(int n, int h, int w, int group_size);
+int g3_render_workspace_init(void* workspace, int n, int h, int w, int group_size, void* stream);
+int g3_render_items_f32(const float* points_src, const float* image_src, const float* mask_src, const uint8_t* boundary_src,
+                        const int* src_index, const float* w2c, const float* K, const float* Kinv, void* workspace, float* frame, float* mask,
+                        float* depth, float* flow_out, int n, int n_src, int h, int w, int group_size, void* stream);
 int g3_mesh_occlusion_f32(const float* cam_points, const uint8_t* boundary_mask, const float* K, const float* Kinv,
                           float* pts_ds, uint8_t* mask_ds, void* tmin, float* frame, float* mask, float* depth, int n, int h,
                           int w, int factor, void* stream);

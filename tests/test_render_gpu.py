@@ -212,3 +212,42 @@ def test_window_splat_matches_atomic_splat(zoom):
     print(f"[window vs atomic splat zoom={zoom}] masks equal, coverage {float(m1.mean()):.3f}; colour outliers {int(bad.sum())}/{bad.numel()}, max abs {float(err.max()):.3e}")
     assert float(bad.float().mean()) < 1e-5 and float(err.max()) < 5e-2
     torch.testing.assert_close(d1, d2, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("fg", [False, True])
+@pytest.mark.parametrize("n_buf", [1, 2])
+def test_render_items_call_matches_the_expand_and_loop_form(fg, n_buf):
+    """Cache3D.render_cache through g3_render_items_f32 (items name their source view, cached self-cleaning workspace, one preallocated output)
+    against the reference-shaped path (sources expanded per item, forward_warp per chunk): masks (=> every splat index / occlusion decision)
+    identical, colours / depths equal up to the summation order of the float atomics. Rendered TWICE through the cached workspace: the second
+    render must not see anything the first left behind (the accumulator cleans itself) - with cameras that push corners out of the windows."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    h, w, Fn = 96, 160, 7  # odd item count for N = 1: a ragged last pair / chunk
+    depth, img, K = _scene(h, w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                    input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
+    if n_buf == 2:
+        w2 = torch.eye(4, device=dev)
+        w2[0, 3] = -0.15
+        cache.update_cache(t(img[::-1].copy())[None], t(depth * 1.07)[None, None], w2[None], new_intrinsics=t(K)[None], depth_alignment=False)
+    w2cs = torch.stack([torch.from_numpy(_cam(tx=0.05 * i, tz=-0.4 * (i % 3), yaw=0.03 * i)) for i in range(Fn)])[None].to(dev)  # zooming in: corners leave windows
+    Ks = t(K)[None, None].expand(1, Fn, 3, 3).contiguous()
+    outs = {}
+    for items in (True, False, True):
+        renderer._ITEMS_CALL = items
+        try:
+            pix, msk = renderer.Cache3D_Base.render_cache(cache, w2cs, Ks, items_per_launch=4)
+            dep, msk_d = renderer.Cache3D_Base.render_cache(cache, w2cs, Ks, render_depth=True, items_per_launch=4)
+        finally:
+            renderer._ITEMS_CALL = True
+        torch.cuda.synchronize()
+        assert torch.equal(msk, msk_d)
+        outs.setdefault(items, []).append((pix.clone(), msk.clone(), dep.clone()))
+    (p1, m1, d1), (p3, m3, d3) = outs[True]
+    p2, m2, d2 = outs[False][0]
+    assert torch.equal(m1, m2) and torch.equal(m1, m3), "masks differ between the items call and the expand-and-loop form"
+    assert 0.2 < float(m1.mean()) < 1.0
+    for a, b in ((p1, p2), (p3, p2), (d1, d2), (d3, d2)):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"max diff {float((a - b).abs().max()):.3e}"
