@@ -8,8 +8,10 @@ Pinning status: PINNED against the reference's own Python for everything that li
 shims for the absent third-party packages, tests/test_oracle_golden.py replays them). The arithmetic that lives in
 third-party packages which are NOT vendored in the reference is restated from their published semantics and is
 "parity unpinned" (SURVEY.md 8c):
-  * transformer-engine 1.12.0  RMSNorm / DotProductAttention / apply_rotary_pos_emb(fused)  (INSTALL.md:20)
+  * transformer-engine 1.12.0  RMSNorm / DotProductAttention  (INSTALL.md:20)
   * diffusers 0.32.2 EDMEulerScheduler (oracle/sampler_oracle.py)
+TE's apply_rotary_pos_emb IS pinned since round 3: te_rope_fused reproduces bit for bit the reference's own copy of it
+(autoregressive/modules/embedding.py:46-85; tests/golden/te_rope.npz, tests/test_te_rope_golden.py).
 
 Every function cites the reference lines it follows. All math runs in the dtype of the given tensors (use fp32
 weights/inputs for the parity oracle; bf16 reproduces the reference's rounding points for the CPU baseline).

@@ -9,8 +9,12 @@ Restates, with an explicit fp32 operation order, the reference's
 Pinning: PINNED to the reference's own Python for everything except the NVIDIA-Warp kernel - tests/golden/warp_*.npz
 hold outputs of the reference `forward_warp` (imported from /root/reference, CPU tensors) produced by
 tools/gen_golden_warp.py; for the foreground_masking cases the reference's lazy hook
-`_ray_triangle_intersection_func` was pointed at `ray_triangle_intersection` below, because warp-lang is absent
-(that one kernel is restated from its in-repo source and is "parity unpinned").
+`_ray_triangle_intersection_func` was pointed at `ray_triangle_intersection` below, because warp-lang is absent.
+That kernel is pinned since round 3 to the reference's own Warp SOURCE: tools/gen_golden_warp_kernel.py runs the reference's
+ray_triangle_intersection_warp.py (kernel body + host wrapper, unmodified) under tools/wp_standin.py (fp32 scalars / vec3, one
+rounding per operation) inside the reference's forward_warp; its outputs equal the warp_small goldens and ray_triangle_depth /
+oracle/c/ray_tri.c reproduce the recorded depth maps bit for bit (tests/golden/warp_kernel_small.npz). What a stand-in cannot
+pin is the instruction selection of a real Warp / NVRTC build (fma contraction inside dot / cross).
 
 Integer / boolean products (pixel indices, masks) are exact; float products depend on atomics order in the reference
 itself (index_put_ accumulate) and on libm (log1p/exp), and are compared with a tolerance.
