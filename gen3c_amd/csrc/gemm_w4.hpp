@@ -149,7 +149,13 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
     }
 }
 
-template <int EPI>
+// PERSIST (g3_set_option("gemm_persistent", 1); OFF by default - measured equal to 8 % slower in round 3, profiles/r3_gemm_persistent_ab.txt: the
+// hardware's workgroup turnover was never the cost, and the residual epilogues lose their full prefetch): one workgroup per CU walks output
+// tiles L = blockIdx.x, + gridDim.x, ... (same XCD-aware order). Between two tiles nothing of the
+// K loop changes; what moves is the dead time around it: the next tile's first LDS stage is requested BEFORE the current tile's epilogue
+// (which then transposes through the idle second stage instead of the first), so neither a workgroup dispatch nor the first stage's
+// LDS-DMA latency sits between two K loops - only the epilogue itself, whose stores drain under the next tile's accumulator clear.
+template <int EPI, bool PERSIST = false>
 __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [stage 2][W tile 256 x 64 | T tile 256 x 64] bf16
     const int tid = threadIdx.x;
@@ -158,83 +164,102 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     const int l31 = lane & 31;
     const int g = lane >> 5;
 
-    // XCD-aware tile order (as gemm_bf16_nt_pp_kernel)
+    // XCD-aware tile order (as gemm_bf16_nt_pp_kernel): logical tile L -> (m0, n0)
     const int nblk = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        bid = base + slot;
-    }
-    int tile_m, tile_n;
-    if (p.tile_order_rowmajor == 1) {
-        tile_m = bid / p.tiles_n;
-        tile_n = bid - tile_m * p.tiles_n;
-    } else {
-        const int GM = p.tile_order_rowmajor >= 2 ? p.tile_order_rowmajor : 4;  // option values >= 2: super-row height for A/B runs
-        const int per_group = GM * p.tiles_n;
-        const int grp = bid / per_group;
-        const int within = bid - grp * per_group;
-        const int gm = min(GM, p.tiles_m - grp * GM);
-        tile_n = within / gm;
-        tile_m = grp * GM + (within - tile_n * gm);
-    }
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
     const int wn = wave & 1;   // feature half of the block tile
     const int wm = wave >> 1;  // token half
-
+    auto tile_origin = [&](int bid, int& m0_out, int& n0_out) {
+        {
+            const int q = nblk >> 3, r = nblk & 7;
+            const int xcd = bid & 7, slot = bid >> 3;
+            const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            bid = base + slot;
+        }
+        int tile_m, tile_n;
+        if (p.tile_order_rowmajor == 1) {
+            tile_m = bid / p.tiles_n;
+            tile_n = bid - tile_m * p.tiles_n;
+        } else {
+            const int GM = p.tile_order_rowmajor >= 2 ? p.tile_order_rowmajor : 4;  // option values >= 2: super-row height for A/B runs
+            const int per_group = GM * p.tiles_n;
+            const int grp = bid / per_group;
+            const int within = bid - grp * per_group;
+            const int gm = min(GM, p.tiles_m - grp * GM);
+            tile_n = within / gm;
+            tile_m = grp * GM + (within - tile_n * gm);
+        }
+        m0_out = tile_m * BM;
+        n0_out = tile_n * BN;
+    };
+    int L = blockIdx.x;
+    int m0, n0;
+    tile_origin(L, m0, n0);
 
     // ---- LDS-DMA: wave w stages rows [64 w, 64 w + 64) of both tiles, 8 pieces of 8 rows each; lane -> row 8 q + (lane >> 3), physical chunk
     // lane & 7 holding logical chunk (lane & 7) ^ ((row >> 1) & 7). Per-lane byte offsets from the tile's first row, rows clamped to the matrix.
     uint32_t vo_w[8], vo_t[8];
+    const char* w_tile;
+    const char* t_tile;
+    auto setup_sources = [&](int m0s, int n0s) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = wave * 64 + 8 * q + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int nrow = min(n0 + r, p.N - 1) - n0, mrow = min(m0 + r, p.M - 1) - m0;  // may be negative only if the tile is empty (never launched)
-        vo_w[q] = (uint32_t)((int64_t)nrow * p.ldw * 2 + chunk * 16);
-        vo_t[q] = (uint32_t)((int64_t)mrow * p.lda * 2 + chunk * 16);
-    }
+        for (int q = 0; q < 8; ++q) {
+            const int r = wave * 64 + 8 * q + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            const int nrow = min(n0s + r, p.N - 1) - n0s, mrow = min(m0s + r, p.M - 1) - m0s;  // may be negative only if the tile is empty (never launched)
+            vo_w[q] = (uint32_t)((int64_t)nrow * p.ldw * 2 + chunk * 16);
+            vo_t[q] = (uint32_t)((int64_t)mrow * p.lda * 2 + chunk * 16);
+        }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(vo_w[q]), "+v"(vo_t[q]));  // keep them resident
-    const char* w_tile = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
-    const char* t_tile = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
+        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(vo_w[q]), "+v"(vo_t[q]));  // keep them resident
+        w_tile = reinterpret_cast<const char*>(p.W + (int64_t)n0s * p.ldw);
+        t_tile = reinterpret_cast<const char*>(p.A + (int64_t)m0s * p.lda);
+    };
+    setup_sources(m0, n0);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const uint32_t m0_w = lds0 + (uint32_t)wave * 8192u, m0_t = lds0 + GW4_T_OFF + (uint32_t)wave * 8192u;  // + stage * 64 KiB
 
+    if (lds0 & 127u) __builtin_trap();  // the XOR form needs the tiles 128-byte aligned (they are: no static LDS in this kernel)
+
+    const int nk = p.K / BK;
+    // ---- prologue pieces: K tile 0 complete (stage 0), the weight rows 0..5 of K tile 1 (stage 1: what k-step 3 of "tile -1" would have issued)
+    auto dma8 = [&](const char* base, const uint32_t (&vo)[8], uint32_t dst) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + vo[q]),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 1024u * q), 16, 0, 0);
+    };
+    auto issue_stage0 = [&]() {
+        dma8(w_tile, vo_w, m0_w);
+        dma8(t_tile, vo_t, m0_t);
+    };
+    auto issue_w1 = [&]() {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + 128 + vo_w[q]),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
+    };
+    issue_stage0();
+    issue_w1();
+  for (;;) {  // output tiles of this workgroup (one unless PERSIST)
     // ---- fragment read addresses (stage 0, row block 0): row * 128 + ((2 ks + g) ^ ((row >> 1) & 7)) * 16 = address(ks = 0) ^ (ks << 5)
-    // one set per stage: a ds_read immediate offset has 16 bits and the second stage starts at 64 KiB
+    // one set per stage: a ds_read immediate offset has 16 bits and the second stage starts at 64 KiB. (Re)derived per output tile from an
+    // opaque copy of the LDS base: in the persistent form they must not stay live across the epilogue, which needs the registers.
     uint32_t adw[2][4], adt[2][4];
     {
+        uint32_t ldsb = lds0;
+        asm volatile("" : "+s"(ldsb));
         const uint32_t c0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                adw[st][ks] = ((lds0 + (uint32_t)((wn * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
-                adt[st][ks] = ((lds0 + (uint32_t)((wm * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
+                adw[st][ks] = ((ldsb + (uint32_t)((wn * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
+                adt[st][ks] = ((ldsb + (uint32_t)((wm * 128 + l31) * 128) + c0) ^ (uint32_t)(ks << 5)) + (uint32_t)(st * GW4_STAGE_BYTES);
             }
     }
-    if (lds0 & 127u) __builtin_trap();  // the XOR form needs the tiles 128-byte aligned (they are: no static LDS in this kernel)
-
-    const int nk = p.K / BK;
-    // ---- prologue: tile 0 complete and the weight rows of tile 1 in flight; the first fragments of tile 0 into buffer 0
     {
-        auto dma8 = [&](const char* base, const uint32_t (&vo)[8], uint32_t dst) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + vo[q]),
-                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(dst + 1024u * q), 16, 0, 0);
-        };
-        dma8(w_tile, vo_w, m0_w);
-        dma8(t_tile, vo_t, m0_t);
-#pragma unroll
-        for (int q = 0; q < 6; ++q)  // weight pieces 0..5 of tile 1 (what k-step 3 of "tile -1" would have issued)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + 128 + vo_w[q]),
-                                             (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
-        // the 256 accumulator writes run while the first tile's LDS-DMA is in flight (one wave per SIMD: nothing else would cover its latency)
+        // the 256 accumulator writes run while the first tile's LDS-DMA is in flight (one wave per SIMD: nothing else would cover its latency;
+        // PERSIST: under the drain of the previous tile's stores - vmcnt counts them too)
         static_for<0, 256>([&](auto rc) { gw4_acc_zero<decltype(rc)::value>(); });
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();
@@ -285,18 +310,24 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     constexpr bool HAS_RES = (EPI == EPI_GATED_RESIDUAL || EPI == EPI_BIAS_RESIDUAL);
     const int rsub = lane >> 4, c2 = lane & 15;
     bf16x8 rpre[HAS_RES ? 4 : 1][HAS_RES ? 8 : 1];
-    auto prefetch_residual = [&]() {
+    // token blocks [J0, J1). Non-persistent: all four before the last K tile. PERSIST: blocks 0, 1 there, blocks 2, 3 behind the K loop (their
+    // latency hides under the epilogue of blocks 0, 1) - all four plus the next tile's source offsets do not fit (77 spills).
+    auto prefetch_residual = [&](auto j0c, auto j1c) {
         if constexpr (HAS_RES) {
             const int n = n0 + wn * 128 + 8 * c2;
-#pragma unroll
-            for (int J = 0; J < 4; ++J)
+            static_for<decltype(j0c)::value, decltype(j1c)::value>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const int m = m0 + wm * 128 + 32 * J + 4 * s8 + rsub;
                     rpre[J][s8] = (m < p.M && n < p.N) ? load_bf16x8(p.R + (int64_t)m * p.ldr + n) : zero_bf16x8();
                 }
+            });
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using ISPLIT = std::integral_constant<int, PERSIST ? 2 : 4>;
+    using I4 = std::integral_constant<int, 4>;
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
     using S0 = std::integral_constant<int, 0>;
@@ -309,13 +340,14 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     if (nk - t == 3) {
         ktile(S0{}, T_{}, T_{}, T_{}, t);
         ktile(S1{}, T_{}, F_{}, T_{}, t + 1);
-        prefetch_residual();
+        prefetch_residual(I0{}, ISPLIT{});
         ktile(S0{}, F_{}, F_{}, F_{}, t + 2);
     } else {  // 2 tiles left
         ktile(S0{}, T_{}, F_{}, T_{}, t);
-        prefetch_residual();
+        prefetch_residual(I0{}, ISPLIT{});
         ktile(S1{}, F_{}, F_{}, F_{}, t + 1);
     }
+    prefetch_residual(ISPLIT{}, I4{});
 
     // ---- epilogue: the accumulators leave the AGPRs one 32-token block (64 registers) at a time and go through the full-line LDS transpose of
     // the other kernels (store_tile_lds: private 16 KiB fp32 slice per wave, a lane then owns 8 consecutive features of one token row). At one
@@ -323,8 +355,18 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
     asm volatile("s_nop 7\n\ts_nop 3" ::: GW4_OWNED);  // last MFMA results -> v_accvgpr_read
     __syncthreads();                                     // the operand stages are idle once every wave is past its last fragment read
     if (G3_AB_GW4_ABLATE & 32) return;  // timing ablation: no epilogue at all
+    // PERSIST: the next tile's K tile 0 goes into stage 0 NOW, under the epilogue, which transposes through stage 1 instead
+    const int m0e = m0, n0e = n0;  // this tile's origin, for the epilogue
+    const int Lnext = L + (int)gridDim.x;
+    const bool has_next = PERSIST && Lnext < nblk;
+    if (has_next) {
+        tile_origin(Lnext, m0, n0);
+        setup_sources(m0, n0);
+        issue_stage0();
+    }
     {
-        char* stage = smem_raw + wave * 16384;
+        const int m0 = m0e, n0 = n0e;  // (shadow: everything below addresses the finished tile)
+        char* stage = smem_raw + (PERSIST ? GW4_STAGE_BYTES : 0) + wave * 16384;
         const int n = n0 + wn * 128 + 8 * c2;
         bf16x8 gv1 = zero_bf16x8();
         if (EPI != EPI_NONE && EPI != EPI_GELU && EPI != EPI_QK_NORM_ROPE && p.gate_rows == 1 && n < p.N) gv1 = load_bf16x8(p.gate + n);
@@ -464,23 +506,46 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
             }
         });
     }
+    if (!has_next) break;
+    __syncthreads();  // every wave is done with its stage-1 transpose slice: the next tile's weight rows of K tile 1 may land there
+    asm volatile("" : "+s"(m0), "+s"(n0));  // (opaque: the offsets are derived AGAIN instead of being kept alive across the epilogue)
+    setup_sources(m0, n0);
+    issue_w1();
+    L = Lnext;
+  }
 }
 
 template <int EPI>
 int launch_w4(const GemmParams& p, hipStream_t stream, const char* what) {
     const size_t smem = 2 * GW4_STAGE_BYTES;
     static bool attr_set[64] = {};
+    static int n_cu[64] = {};
     static std::mutex attr_mu;
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipGetDevice failed");
     {
         std::lock_guard<std::mutex> lock(attr_mu);
         if (!attr_set[dev_id]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4_kernel<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if constexpr (EPI != EPI_QK_NORM_ROPE)
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || cus <= 0) cus = 256;
+            n_cu[dev_id] = cus;
             attr_set[dev_id] = true;
         }
     }
-    hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(GW4_THREADS), smem, stream, p);
+    const int nblk = p.tiles_m * p.tiles_n;
+    // persistent form: one workgroup per CU (a multiple of 8 keeps a workgroup's tiles on its XCD's band of the XCD-aware order); only worth it
+    // when a workgroup gets at least two tiles
+    const int grid_p = (n_cu[dev_id] / 8) * 8;
+    if constexpr (EPI != EPI_QK_NORM_ROPE) {  // (the norm / RoPE epilogue's tables do not fit beside the tile state: no persistent form)
+        if (g3_opt_gemm_persistent && grid_p >= 8 && nblk >= 2 * grid_p) {
+            hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<EPI, true>), dim3(grid_p), dim3(GW4_THREADS), smem, stream, p);
+            return g3_check_launch(what);
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<EPI, false>), dim3(nblk), dim3(GW4_THREADS), smem, stream, p);
     return g3_check_launch(what);
 }

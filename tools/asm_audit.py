@@ -112,9 +112,9 @@ def audit_gemm_w4(asm_text: str):
     findings, cur, body = [], None, []
     funcs = {}
     for ln in asm_text.split("\n"):
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4(_conv)?_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4(_conv)?_kernelILi(\d+)E(?:Lb([01])E)?EEvNS_10GemmParamsE):", ln)
         if m:
-            cur = f"gemm_w4{m.group(2) or ''}<{m.group(3)}>"
+            cur = f"gemm_w4{m.group(2) or ''}<{m.group(3)}{', persistent' if m.group(4) == '1' else ''}>"
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(ln)
@@ -127,6 +127,20 @@ def audit_gemm_w4(asm_text: str):
             continue
         lo, hi = mf[0], mf[-1]
         in_asm = False
+        # loop depth of every line (block comments "... Depth=N"); the K-tile loop is the innermost one (depth 1, or 2 inside the persistent
+        # tile loop). A scratch access THERE stalls every K tile on vmcnt(0) together with the tile's LDS-DMA: finding. Outside it (kernel
+        # set-up, between the K loop and the last K tile, epilogue) it costs one wait per OUTPUT tile: reported as a note.
+        depth, depths = 0, []
+        for li, l in enumerate(v):
+            if re.match(r"^\.LBB\d+_\d+:", l) or l.startswith("; %bb."):
+                m_d = re.search(r"Depth=(\d+)", l)
+                depth = int(m_d.group(1)) if m_d else 0
+                for l2 in v[li + 1:li + 4]:  # a loop header's own depth is on the continuation lines ("=>This Inner Loop Header: Depth=N")
+                    m_h = re.search(r"Loop Header: Depth=(\d+)", l2)
+                    if m_h and l2.lstrip().startswith(";"):
+                        depth = int(m_h.group(1))
+            depths.append(depth)
+        max_depth = max(depths[i] for i in mf)  # depth of the K-tile loop = where the bulk of the MFMAs sits (the last K tiles are peeled: one less)
         for i, l in enumerate(v):
             t = l.strip()
             if "ASMSTART" in t:
@@ -138,7 +152,10 @@ def audit_gemm_w4(asm_text: str):
             if not t or t[0] in ";.":
                 continue
             if t.startswith("scratch_"):
-                findings.append(f"{name}: line {i}: scratch access `{t}`")
+                if max_depth > 0 and depths[i] == max_depth and lo <= i <= hi:
+                    findings.append(f"{name}: line {i}: scratch access inside the K-tile loop `{t}`")
+                elif lo <= i <= hi:
+                    print(f"note: {name}: line {i}: scratch access between K tiles (once per output tile): `{t}`")
             if in_asm or not (lo <= i <= hi):
                 continue
             for m in re.finditer(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b", t):
