@@ -82,9 +82,10 @@ for (M, N, K, epi) in [(56320, 4096, 4096, 2), (7040, 12288, 4096, 0), (4096, 16
     w_ = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
     gate = torch.randn(1, N, device=dev, generator=g).to(torch.bfloat16)
     res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
-    for pp in (0, 1, 2, 3):
+    for pp in (0, 1, 2, 3, 13):  # 13 = one wave per SIMD as a persistent tile loop (round 3; runs where a workgroup gets >= 2 tiles)
         def run(lib):
-            lib.g3_set_option(b"gemm_pingpong", pp)
+            lib.g3_set_option(b"gemm_pingpong", pp % 10)
+            lib.g3_set_option(b"gemm_persistent", 1 if pp == 13 else 0)
             o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             rc = lib.g3_gemm_bf16_nt(a_.data_ptr(), K, w_.data_ptr(), K, o.data_ptr(), N, M, N, K, epi, gate.data_ptr() if epi >= 2 else None, 1, N,
                                      res.data_ptr() if epi in (2, 4) else None, N, st)
@@ -105,18 +106,39 @@ for (C_in, C_out, T, Hh, Ww, kt, kh, kw, st_, sh, sw) in [(128, 256, 5, 48, 64, 
     ot, oh, ow = (-(kt - 1), 0 if sh == 2 else -(kh // 2), 0 if sw == 2 else -(kw // 2))
     if kt == 3 and st_ == 2:
         To = (T - 1) // 2 + 1
-    for pp in (0, 2):
+    resid = torch.randn(To * Ho * Wo, C_out, device=dev, generator=g).to(torch.bfloat16)
+    for (pp, w4, with_res) in ((0, 0, False), (2, 0, False), (2, 1, False), (2, 1, True), (2, 0, True)):  # w4 = 1: gemm_w4_conv.hpp (round 3)
         def run(lib):
             lib.g3_set_option(b"gemm_pingpong", pp)
+            lib.g3_set_option(b"conv_w4", w4)
             o = torch.empty(To * Ho * Wo, C_out, device=dev, dtype=torch.bfloat16)
-            rc = lib.g3_conv3d_cl_bf16(x_.data_ptr(), C_in, w_.data_ptr(), C_in, bias.data_ptr(), None, 0, o.data_ptr(), C_out, C_in, C_out, T, Hh, Ww, To, Ho, Wo,
-                                       kt, kh, kw, st_, sh, sw, ot, oh, ow, st)
+            rc = lib.g3_conv3d_cl_bf16(x_.data_ptr(), C_in, w_.data_ptr(), C_in, bias.data_ptr(), resid.data_ptr() if with_res else None, C_out, o.data_ptr(), C_out,
+                                       C_in, C_out, T, Hh, Ww, To, Ho, Wo, kt, kh, kw, st_, sh, sw, ot, oh, ow, st)
             assert rc == 0, lib.g3_last_error()
             return o
         x, y = both(run)
-        report(f"conv {C_in}->{C_out} k=({kt},{kh},{kw}) s=({st_},{sh},{sw}) on {T}x{Hh}x{Ww} pingpong={pp}", x, y)
+        report(f"conv {C_in}->{C_out} k=({kt},{kh},{kw}) s=({st_},{sh},{sw}) on {T}x{Hh}x{Ww} pingpong={pp} conv_w4={w4} residual={with_res}", x, y)
+# ---- split-KV attention: partial outputs + merge (round 3)
+for (Sq, Skv, H, variant) in [(7040, 14080, 4, 11), (7040, 14080, 4, 4), (1000, 448, 2, 4)]:
+    q = torch.randn(Sq, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(v, Skv, 1, H)
+    ld = vt.shape[-1]
+
+    def run(lib):
+        op = torch.empty(Sq, H * 128, device=dev, dtype=torch.float32)
+        lse = torch.empty(1, H, Sq, device=dev, dtype=torch.float32)
+        rc = lib.g3_flash_attn_fwd_ex_bf16(q.data_ptr(), H * 128, H * 128, 128, k.data_ptr(), H * 128, H * 128, 128, vt.data_ptr(), ld, H * 128 * ld, 128 * ld, 0, 0,
+                                           None, op.data_ptr(), lse.data_ptr(), H * 128, H * 128, 128, Sq, Skv, 1, H, 128, 1.0 / math.sqrt(128), variant, st)
+        assert rc == 0, lib.g3_last_error()
+        return torch.cat([op.reshape(-1), lse.reshape(-1)])
+    a, b = both(run)
+    report(f"split-KV partial attention Sq={Sq} Skv={Skv} H={H} variant={variant}", a, b)
 for lib in (base, alt):
     lib.g3_set_option(b"attn_variant", 0)
     lib.g3_set_option(b"gemm_pingpong", 3)
+    lib.g3_set_option(b"gemm_persistent", 0)
+    lib.g3_set_option(b"conv_w4", 1)
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FOUND {bad} DIFFERENCES")
 sys.exit(1 if bad else 0)

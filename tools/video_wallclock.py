@@ -66,7 +66,7 @@ for name in ("encode", "decode"):
     setattr(model, name, (lambda o, n: (lambda *a, **k: timed("tokenizer_" + n, o, *a, **k)))(orig, name))
 cond_image = (img[:, :, None] * 0.99).to(torch.bfloat16)
 emb = torch.zeros(1, 512, net.crossattn_emb_channels, dtype=torch.bfloat16)
-video = timed("pipeline_generate_total", pipe.generate, emb, cond_image, renders, masks)
+video = timed("pipeline_generate_total", pipe.generate_from_embeddings, emb, cond_image, renders, masks)
 assert video.shape == (T, H, W, 3)
 times["denoise_loop_and_glue"] = times["pipeline_generate_total"] - times.get("tokenizer_encode", 0) - times.get("tokenizer_decode", 0)
 times["video_total_excl_model_build"] = times["cache_build"] + times["render_121_frames"] + times["pipeline_generate_total"]
