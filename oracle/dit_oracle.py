@@ -28,7 +28,7 @@ import torch.nn.functional as F
 def timestep_sinusoid(timesteps: torch.Tensor, dim: int) -> torch.Tensor:
     """Timesteps.forward - cos|sin halves, fp32 internally (module/blocks.py:38-51)."""
     half = dim // 2
-    expo = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - 0.0)
+    expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / (half - 0.0)
     ang = timesteps[:, None].float() * torch.exp(expo)[None, :]
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).to(timesteps.dtype)
 
@@ -55,8 +55,8 @@ def rope_freqs(seq: torch.Tensor, head_dim: int, T: int, H: int, W: int, fps: Op
     dim_h = head_dim // 6 * 2
     dim_w = dim_h
     dim_t = head_dim - 2 * dim_h
-    rs = torch.arange(0, dim_h, 2)[: dim_h // 2].float() / dim_h
-    rt = torch.arange(0, dim_t, 2)[: dim_t // 2].float() / dim_t
+    rs = torch.arange(0, dim_h, 2, device=seq.device)[: dim_h // 2].float() / dim_h
+    rt = torch.arange(0, dim_t, 2, device=seq.device)[: dim_t // 2].float() / dim_t
     h_theta = 10000.0 * h_ratio ** (dim_h / (dim_h - 2))
     w_theta = 10000.0 * w_ratio ** (dim_w / (dim_w - 2))
     t_theta = 10000.0 * t_ratio ** (dim_t / (dim_t - 2))
