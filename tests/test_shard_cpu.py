@@ -66,6 +66,8 @@ def _worker(rank, world, port, tmp):
     parallel.parallel_state.initialize_model_parallel(context_parallel_size=world)
     group = parallel.parallel_state.get_context_parallel_group()
     renderer.forward_warp = _oracle_forward_warp
+    renderer._ITEMS_CALL = False  # the expand-and-loop form calls forward_warp (the stand-in); the item ranges / pair sharding / gather are shared with the
+    # one-call form (g3_render_items_f32), whose sharded == replicated check runs with the real kernels in tools/cp_check.py (tests/test_cp_gpu.py)
     try:
         # --- unit ranges cover everything exactly once, contiguous, balanced
         for n in (0, 1, 5, 121, 242):
