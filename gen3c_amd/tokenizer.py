@@ -349,6 +349,7 @@ class VideoTokenizer:
         self.spatial_resolution = spatial_resolution
         self.net = CausalVideoTokenizerNet(channels=channels, latent_channels=latent_ch, device=device)
         self.latent_mean = self.latent_std = None
+        self.image_latent_mean = self.image_latent_std = None
 
     # -- weights
     def load_weights(self, vae_dir: str):
@@ -360,12 +361,23 @@ class VideoTokenizer:
         self.net.load_state_dict(sd, strict=True)
         mean, std = torch.load(os.path.join(vae_dir, "mean_std.pt"), weights_only=True)
         self.register_mean_std(mean, std)
+        img_stats = os.path.join(vae_dir, "image_mean_std.pt")  # the image half of the joint tokenizer shares encoder / decoder, not the statistics
+        if os.path.exists(img_stats):
+            self.register_image_mean_std(*torch.load(img_stats, weights_only=True))
 
     def register_mean_std(self, latent_mean: torch.Tensor, latent_std: torch.Tensor):
         t = self.latent_chunk_duration
         shape = [1, self.latent_ch, t, 1, 1]
         self.latent_mean = latent_mean.view(self.latent_ch, -1)[:, :t].to(self.dtype).reshape(shape).to(self.net.dev)
         self.latent_std = latent_std.view(self.latent_ch, -1)[:, :t].to(self.dtype).reshape(shape).to(self.net.dev)
+
+    def register_image_mean_std(self, latent_mean: torch.Tensor, latent_std: torch.Tensor):
+        """Per-channel latent statistics of the IMAGE branch (`image_mean_std.pt`, BasePretrainedImageVAE.register_mean_std,
+        pretrained_vae.py:110-124): JointImageVideoSharedJITTokenizer routes T == 1 inputs through the same encoder / decoder with these
+        (pretrained_vae.py:520-545, 588-611). GEN3C's entry points never encode a single frame; the branch exists for the plug-in's completeness."""
+        shape = [1, self.latent_ch, 1, 1, 1]
+        self.image_latent_mean = latent_mean.to(self.dtype).reshape(shape).to(self.net.dev)
+        self.image_latent_std = latent_std.to(self.dtype).reshape(shape).to(self.net.dev)
 
     def reset_dtype(self, *a, **k):
         return None  # weights are bf16 by construction
@@ -418,8 +430,12 @@ class VideoTokenizer:
     def encode(self, state: torch.Tensor) -> torch.Tensor:
         """[B,3,T,H,W] in [-1,1] -> [B,16,T_lat,H/8,W/8], (z - mean) / std per (channel, latent frame)."""
         B, C, T, H, W = state.shape
-        assert T % self._pixel_chunk == 0, f"Temporal dimension {T} is not divisible by chunk_length {self._pixel_chunk}"
         in_dtype = state.dtype
+        if T == 1:  # image branch of the joint tokenizer (JointImageVideoTokenizer.encode, pretrained_vae.py:531-537)
+            assert getattr(self, "image_latent_mean", None) is not None, "image branch: register_image_mean_std / image_mean_std.pt missing"
+            z = torch.cat([self.net.encoder(state[b:b + 1].to(self.net.dev)) for b in range(B)], dim=0)
+            return (z.to(in_dtype) - self.image_latent_mean.to(in_dtype)) / self.image_latent_std.to(in_dtype)
+        assert T % self._pixel_chunk == 0, f"Temporal dimension {T} is not divisible by chunk_length {self._pixel_chunk}"
         outs = []
         for b in range(B):
             chunks = []
@@ -434,8 +450,12 @@ class VideoTokenizer:
     def decode(self, latent: torch.Tensor) -> torch.Tensor:
         B, _, T, _, _ = latent.shape
         tl = self.latent_chunk_duration
-        assert T % tl == 0, f"Temporal dimension {T} is not divisible by chunk_length {tl}"
         in_dtype = latent.dtype
+        if T == 1 and tl != 1:  # image branch (JointImageVideoTokenizer.decode, pretrained_vae.py:539-544)
+            assert getattr(self, "image_latent_mean", None) is not None, "image branch: register_image_mean_std / image_mean_std.pt missing"
+            z = latent.to(self.net.dev) * self.image_latent_std.to(in_dtype) + self.image_latent_mean.to(in_dtype)
+            return torch.cat([self.net.decoder(z[b:b + 1].to(self.dtype)) for b in range(B)], dim=0).to(in_dtype)
+        assert T % tl == 0, f"Temporal dimension {T} is not divisible by chunk_length {tl}"
         outs = []
         for b in range(B):
             chunks = []
