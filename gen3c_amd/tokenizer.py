@@ -280,6 +280,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         """encoder_jit: [1,3,T,H,W] (T = 1+8k, H,W % 8 == 0) -> [1,16,1+k,H/8,W/8]  (layers3d.py:793-818)."""
         assert video.dim() == 5 and video.shape[0] == 1 and video.shape[1] == 3, "one clip at a time (the reference encodes B=1 chunks)"
         _, _, T, H, W = video.shape
+        self._pending_stats = None
         vid = video[0].to(bf16).contiguous()
         Tp, Hp, Wp = (T + 3) // 4, H // 4, W // 4
         h = torch.empty((Tp, Hp, Wp, 192), dtype=bf16, device=vid.device)
@@ -302,12 +303,14 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         h = self._conv(h, "encoder.conv_out.0", "s3")
         h = self._conv(h, "encoder.conv_out.1", "t3")
         h = self._conv(h, "quant_conv", "p1")
+        self._pending_stats = None  # (do not keep the last producer's output alive)
         return h.permute(3, 0, 1, 2).unsqueeze(0).contiguous()
 
     @torch.no_grad()
     def decoder(self, z: torch.Tensor) -> torch.Tensor:
         """decoder_jit: [1,16,t,h,w] -> [1,3,1+8(t-1),8h,8w]  (layers3d.py:930-949)."""
         assert z.dim() == 5 and z.shape[0] == 1
+        self._pending_stats = None
         h = z[0].to(bf16).permute(1, 2, 3, 0).contiguous()
         h = self._conv(h, "post_quant_conv", "p1")
         h = self._conv(h, "decoder.conv_in.0", "s3")
@@ -332,6 +335,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         Tp, Hp, Wp, _ = h.shape
         vid = torch.empty((3, 4 * Tp - 3, 4 * Hp, 4 * Wp), dtype=bf16, device=h.device)
         _lib.check(_lib.load().g3_haar3d_unpatch_bf16(_ptr(h), 192, _ptr(vid), Tp, Hp, Wp, _st()), "g3_haar3d_unpatch_bf16")
+        self._pending_stats = None
         return vid.unsqueeze(0)
 
 
