@@ -293,6 +293,12 @@ class VideoExtendGeneralDIT(nn.Module):
         self.cp_group = cp_group
         self.cp_size = dist.get_world_size(cp_group)
         self._cp_attn = ContextParallelAttention(cp_group)
+        # G3_CP_CONFIG="<head groups>,<auto|w4b|wave8>,<gather_first|local_first>": the configuration `python bench.py --gpus N` measured fastest on
+        # this node (its `cp.chosen`), for the entry points that do not tune themselves (gen3c_single_image.py --num_gpus N, ...)
+        cfg = __import__("os").environ.get("G3_CP_CONFIG")
+        if cfg:
+            g_, kern_, sched_ = (c.strip() for c in cfg.split(","))
+            self._cp_attn.configure(head_groups=int(g_), kernel=kern_, schedule=sched_)
         self._tables.clear()
 
     def disable_context_parallel(self):
