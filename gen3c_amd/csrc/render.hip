@@ -290,8 +290,30 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     const int ty0 = (blockIdx.x / tiles_x) * TS, tx0 = (blockIdx.x % tiles_x) * TS;
     const int64_t slot = (int64_t)item * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
-    for (int i = threadIdx.x; i < WIN * WIN * ACC_C; i += 256) win[i] = 0.f;
-    for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
+    // All 28 loads of the thread's four pixels go out first, unconditionally (an out-of-image pixel reads pixel 0 and is switched off below): with
+    // the loads behind `if (mask != 0)` every pixel paid two dependent HBM round trips and a workgroup - LDS holds only four per CU - sat idle
+    // through eight of them. The zero fill of the window runs underneath them.
+    float mk[4], zin[4], flx[4], fly[4], rgb[4][3];
+    bool inb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);  // a thread owns 4 consecutive rows of one column
+        inb[k] = py < h && px < w;
+        const int pix = inb[k] ? py * w + px : 0;
+        const int64_t o = (int64_t)item * hw + pix;
+        mk[k] = maskz[o];
+        zin[k] = zbuf[o];
+        flx[k] = flow[((int64_t)item * 2 + 0) * hw + pix];
+        fly[k] = flow[((int64_t)item * 2 + 1) * hw + pix];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[k][c] = image[((int64_t)sitem * 3 + c) * hw + pix];
+    }
+    {
+        f32x4* wz = reinterpret_cast<f32x4*>(win);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < WIN * WIN * ACC_C / 4; i += 256) wz[i] = zero4;
+        for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
+    }
     __syncthreads();
 
     SplatGeom g[4];
@@ -300,23 +322,18 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     int mnx = 0x7fffffff, mny = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);  // a thread owns 4 consecutive rows of one column
-        on[k] = false;
-        if (py >= h || px >= w) continue;
-        const int pix = py * w + px;
-        const int64_t o = (int64_t)item * hw + pix;
-        const float m = maskz[o];
-        if (m == 0.f) continue;
-        on[k] = true;
-        const float z = zbuf[o];
-        g[k] = splat_geom(flow[((int64_t)item * 2 + 0) * hw + pix], flow[((int64_t)item * 2 + 1) * hw + pix], px, py, h, w);
+        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
+        on[k] = inb[k] && mk[k] != 0.f;
+        if (!on[k]) continue;
+        const float z = zin[k];
+        g[k] = splat_geom(flx[k], fly[k], px, py, h, w);
         const float logd = log1pf(fmaxf(z, 0.f));
         const float expo = logd / (lmax + 1e-7f) * 50.0f;
         const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
         wscale[k] = dw;
-        col[k][0] = image[((int64_t)sitem * 3 + 0) * hw + pix];
-        col[k][1] = image[((int64_t)sitem * 3 + 1) * hw + pix];
-        col[k][2] = image[((int64_t)sitem * 3 + 2) * hw + pix];
+        col[k][0] = rgb[k][0];
+        col[k][1] = rgb[k][1];
+        col[k][2] = rgb[k][2];
         col[k][3] = z;
         mnx = min(mnx, g[k].fx);
         mny = min(mny, g[k].fy);
@@ -332,98 +349,185 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
     if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
     // Accumulate into the window. A thread owns 4 consecutive rows of one column; a wave 8 rows x 32 columns (lanes 0..31: rows 8 v .. 8 v + 3,
-    // lanes 32..63: rows 8 v + 4 .. 8 v + 7). Under a smooth flow the east corners of pixel x are the west corners of pixel x + 1 and the south
-    // corners of row y the north corners of row y + 1, so before any atomic the contributions that meet in one destination texel are summed in
-    // registers: a lane takes over its left neighbour's east column (DPP wave shift), a row takes over the south-west texel of the row above
-    // it (inside the thread; across the wave's halves with v_permlane32_swap); the donor skips those adds. Same contributions, ~6 instead of
-    // 20 LDS float atomics per pixel - and those atomics are what bounds this kernel (see above). Every lane runs the cross-lane moves.
+    // lanes 32..63: rows 8 v + 4 .. 8 v + 7). LDS float atomics are what bounds this kernel (see above: ~6 LDS cycles per LANE), so contributions
+    // that meet in one destination texel are summed in registers first and every texel then gets, as far as possible, ONE plain store.
+    // A pixel has a west and an east pair of corners; each corner is (texel id = y << 16 | x, 5 values) and id -1 means "nothing left to write".
+    //   (1) inside the pixel: corners that coincide (floor == ceil on an integer coordinate) are summed;
+    //   (2) across lanes: the east corners of lane i - 1 (DPP wave shift) are added to ANY west corner of lane i with the same texel in rows
+    //       k - 1 .. k + 1. Under the reference's default trajectories (camera moving along x) flow_y is 0 up to rounding, so a row's y lands on,
+    //       just below or just above an integer pixel by pixel and "same row, same corner" (the round-2 rule) matched only ~54 % of the
+    //       neighbours; matching by texel id finds a home for ~all of them (tools/render_merge_model.py: 1.7 -> 0.3 atomic corners per pixel);
+    //   (3) down the thread's column, and from the last row of lane i to the first rows of lane i + 32 (v_permlane32_swap): a west corner is
+    //       added to a west corner of the next row with the same texel.
+    // Merging only ever joins equal texel ids, so whatever is left of a chain still carries the id of everything summed into it.
+    // Every lane runs the cross-lane moves (they would read garbage from lanes masked off by a branch).
     const int lane = threadIdx.x & 63;
     const bool upper = lane >= 32;
-    float nwv[4][ACC_C], swv[4][ACC_C], nev[4][ACC_C], sev[4][ACC_C];
-    int fx[4], cx[4], fy[4], cy[4];
-    bool east_given[4], sw_given[4];
+    float Wv[4][2][ACC_C], Ev[4][2][ACC_C];  // [row][0 north / 1 south][r g b z weight]
+    int tw[4][2], te[4][2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        fx[k] = -1; cx[k] = -2; fy[k] = -3; cy[k] = -4;
+        tw[k][0] = tw[k][1] = te[k][0] = te[k][1] = -1;
         if (on[k]) {
-            const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
-            const float m = maskz[(int64_t)item * hw + py * w + px];
+            const float m = mk[k];
             const float dw = wscale[k];
             const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                nwv[k][e] = col[k][e] * wts[0]; swv[k][e] = col[k][e] * wts[1]; nev[k][e] = col[k][e] * wts[2]; sev[k][e] = col[k][e] * wts[3];
+                Wv[k][0][e] = col[k][e] * wts[0]; Wv[k][1][e] = col[k][e] * wts[1]; Ev[k][0][e] = col[k][e] * wts[2]; Ev[k][1][e] = col[k][e] * wts[3];
             }
-            nwv[k][4] = wts[0]; swv[k][4] = wts[1]; nev[k][4] = wts[2]; sev[k][4] = wts[3];
-            fx[k] = g[k].fx; cx[k] = g[k].cx; fy[k] = g[k].fy; cy[k] = g[k].cy;
+            Wv[k][0][4] = wts[0]; Wv[k][1][4] = wts[1]; Ev[k][0][4] = wts[2]; Ev[k][1][4] = wts[3];
+            tw[k][0] = (g[k].fy << 16) | g[k].fx; tw[k][1] = (g[k].cy << 16) | g[k].fx;
+            te[k][0] = (g[k].fy << 16) | g[k].cx; te[k][1] = (g[k].cy << 16) | g[k].cx;
+            // (1) coinciding corners of this pixel
+            if (tw[k][1] == tw[k][0]) {
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) Wv[k][0][e] += Wv[k][1][e];
+                tw[k][1] = -1;
+            }
+            if (te[k][1] == te[k][0]) {
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) Ev[k][0][e] += Ev[k][1][e];
+                te[k][1] = -1;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (te[k][c] < 0) continue;
+                const int cc = te[k][c] == tw[k][0] ? 0 : (te[k][c] == tw[k][1] ? 1 : -1);
+                if (cc < 0) continue;
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) {
+                    if (cc == 0) Wv[k][0][e] += Ev[k][c][e]; else Wv[k][1][e] += Ev[k][c][e];
+                }
+                te[k][c] = -1;
+            }
         } else {
 #pragma unroll
-            for (int e = 0; e < ACC_C; ++e) nwv[k][e] = swv[k][e] = nev[k][e] = sev[k][e] = 0.f;
+            for (int e = 0; e < ACC_C; ++e) Wv[k][0][e] = Wv[k][1][e] = Ev[k][0][e] = Ev[k][1][e] = 0.f;
         }
-        // horizontal: lane i takes lane i - 1's east column when it is this lane's west column
-        const int p_on = lane_prev((int)on[k]), p_cx = lane_prev(cx[k]), p_fy = lane_prev(fy[k]), p_cy = lane_prev(cy[k]);
-        const bool htake = on[k] && p_on && (lane & 31) != 0 && p_cx == fx[k] && p_fy == fy[k] && p_cy == cy[k];
-#pragma unroll
-        for (int e = 0; e < ACC_C; ++e) {
-            const float pne = lane_prev(nev[k][e]), pse = lane_prev(sev[k][e]);
-            if (htake) { nwv[k][e] += pne; swv[k][e] += pse; }
-        }
-        const int n_take = lane_next((int)htake);
-        east_given[k] = n_take != 0 && (lane & 31) != 31;
-        sw_given[k] = false;
     }
-    // vertical, inside the thread: row k + 1 takes row k's south-west texel when it is its own north-west texel
+    // (2) east corners of the left neighbour -> my west corners
+    {
+        unsigned mytake = 0;  // bit 2 k + c: I took east corner (k, c) of lane - 1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int p_t = lane_prev(te[k][c]);
+                float pv[ACC_C];
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) pv[e] = lane_prev(Ev[k][c][e]);
+                const bool can = (lane & 31) != 0 && p_t >= 0;  // lanes 0 / 32 have no left neighbour in their rows
+                bool done = false;
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int j = dj == 0 ? k : (dj == 1 ? k - 1 : k + 1);
+                    if (j < 0 || j > 3) continue;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const bool hit = can && !done && tw[j][cc] == p_t;
+                        if (hit) {
+#pragma unroll
+                            for (int e = 0; e < ACC_C; ++e) Wv[j][cc][e] += pv[e];
+                        }
+                        done = done || hit;
+                    }
+                }
+                if (done) mytake |= 1u << (2 * k + c);
+            }
+        }
+        const unsigned n_take = (unsigned)lane_next((int)mytake);
+        const unsigned given = (lane & 31) != 31 ? n_take : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if ((given >> (2 * k + c)) & 1u) te[k][c] = -1;
+    }
+    // (3) down the column inside the thread
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const bool vt = on[k] && on[k + 1] && fx[k] == fx[k + 1] && cy[k] == fy[k + 1];
-        if (vt) {
 #pragma unroll
-            for (int e = 0; e < ACC_C; ++e) nwv[k + 1][e] += swv[k][e];
-            sw_given[k] = true;
+        for (int c = 0; c < 2; ++c) {
+            bool done = false;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const bool hit = !done && tw[k][c] >= 0 && tw[k + 1][cc] == tw[k][c];
+                if (hit) {
+#pragma unroll
+                    for (int e = 0; e < ACC_C; ++e) Wv[k + 1][cc][e] += Wv[k][c][e];
+                }
+                done = done || hit;
+            }
+            if (done) tw[k][c] = -1;
         }
     }
-    // vertical, across the wave's halves: the first row of lane i + 32 takes the south-west texel of the last row of lane i
+    // ... and across the wave's halves: the west corners of the last row of lane i -> the first two rows of lane i + 32
     {
-        const int l_on = from_lane_minus32((int)on[3]), l_fx = from_lane_minus32(fx[3]), l_cy = from_lane_minus32(cy[3]);
-        const bool vtake = upper && on[0] && l_on && l_fx == fx[0] && l_cy == fy[0];
+        unsigned mytake = 0;
 #pragma unroll
-        for (int e = 0; e < ACC_C; ++e) {
-            const float lsw = from_lane_minus32(swv[3][e]);
-            if (vtake) nwv[0][e] += lsw;
+        for (int c = 0; c < 2; ++c) {
+            const int l_t = from_lane_minus32(tw[3][c]);
+            float lv[ACC_C];
+#pragma unroll
+            for (int e = 0; e < ACC_C; ++e) lv[e] = from_lane_minus32(Wv[3][c][e]);
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const bool hit = upper && !done && l_t >= 0 && tw[j][cc] == l_t;
+                    if (hit) {
+#pragma unroll
+                        for (int e = 0; e < ACC_C; ++e) Wv[j][cc][e] += lv[e];
+                    }
+                    done = done || hit;
+                }
+            }
+            if (done) mytake |= 1u << c;
         }
-        const int u_take = from_lane_plus32((int)vtake);  // evaluated by EVERY lane: inside `!upper && ...` the swap would run with half the wave masked off
-        if (!upper && u_take != 0) sw_given[3] = true;
+        const unsigned u_take = (unsigned)from_lane_plus32((int)mytake);  // evaluated by EVERY lane: inside `!upper && ...` the swap would run with half the wave masked off
+        if (!upper) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if ((u_take >> c) & 1u) tw[3][c] = -1;
+        }
     }
-    // After the merge almost every destination texel receives exactly one value: the (merged) north-west contribution of one pixel. LDS float
-    // atomics cost ~6 LDS cycles per LANE (PMC), plain stores 2 cycles per wave instruction, so the texels are first given an owner: every
-    // pixel writes its id to owner[its NW texel] (last writer wins), and after a barrier the pixel that reads its own id back STORES its five
-    // values into the zero-initialised window; everything else - pixels that lost a texel, unmerged south-west / east contributions,
-    // out-of-window corners - follows after a second barrier as atomics, as before.
-    int nw_tex[4];
+    // After the merge almost every destination texel receives exactly one value. LDS float atomics cost ~6 LDS cycles per LANE (PMC), plain
+    // stores 2 cycles per wave instruction, so the texels are first given an owner: every west corner still alive writes its id to
+    // owner[its texel] (last writer wins), and after a barrier the corner that reads its own id back STORES its five values into the
+    // zero-initialised window; everything else - corners that lost a texel, east corners nobody took, out-of-window corners - follows
+    // after a second barrier as atomics.
+    int wl[4][2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        nw_tex[k] = -1;
-        if (!on[k]) continue;
-        const int lx = fx[k] - ox, ly = fy[k] - oy;
-        if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
-            nw_tex[k] = ly * WIN + lx;
-            owner[nw_tex[k]] = k * 256 + (int)threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            wl[k][c] = -1;
+            if (tw[k][c] < 0) continue;
+            const int lx = (tw[k][c] & 0xffff) - ox, ly = (tw[k][c] >> 16) - oy;
+            if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
+                wl[k][c] = ly * WIN + lx;
+                owner[wl[k][c]] = (2 * k + c) * 256 + (int)threadIdx.x;
+            }
         }
     }
     __syncthreads();
-    bool nw_done[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        nw_done[k] = false;
-        if (nw_tex[k] >= 0 && owner[nw_tex[k]] == k * 256 + (int)threadIdx.x) {
-            float* a = win + nw_tex[k] * ACC_C;
 #pragma unroll
-            for (int e = 0; e < ACC_C; ++e) a[e] = nwv[k][e];
-            nw_done[k] = true;
+        for (int c = 0; c < 2; ++c) {
+            if (wl[k][c] >= 0 && owner[wl[k][c]] == (2 * k + c) * 256 + (int)threadIdx.x) {
+                float* a = win + wl[k][c] * ACC_C;
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) a[e] = Wv[k][c][e];
+                tw[k][c] = -1;
+            }
         }
     }
     __syncthreads();
-    auto add_texel = [&](int x, int y, const float (&v)[ACC_C]) {
+    auto add_texel = [&](int tex, const float (&v)[ACC_C]) {
+        const int x = tex & 0xffff, y = tex >> 16;
         const int lx = x - ox, ly = y - oy;
         if ((unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
             float* a = win + (ly * WIN + lx) * ACC_C;
@@ -438,12 +542,10 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!on[k]) continue;
-        if (!nw_done[k]) add_texel(fx[k], fy[k], nwv[k]);
-        if (!sw_given[k]) add_texel(fx[k], cy[k], swv[k]);
-        if (!east_given[k]) {
-            add_texel(cx[k], fy[k], nev[k]);
-            add_texel(cx[k], cy[k], sev[k]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (tw[k][c] >= 0) add_texel(tw[k][c], Wv[k][c]);
+            if (te[k][c] >= 0) add_texel(te[k][c], Ev[k][c]);
         }
     }
     __syncthreads();
@@ -818,6 +920,7 @@ extern "C" int g3_warp_splat_resolve_f32(const float* image, const float* z, con
         return g3_set_error(G3_ERR_ARG, "g3_warp_splat_resolve_f32: null operand");
     if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_resolve_f32: bad shape");
     if ((uintptr_t)workspace & 15) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_resolve_f32: workspace must be 16-byte aligned");
+    if (h + 2 > 32767 || w + 2 > 65535) return g3_set_error(G3_ERR_ARG, "g3_warp_splat_resolve_f32: image too large for the packed texel ids (h < 32766, w < 65534)");
     const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
     float* windows = (float*)workspace;
     int* origins = (int*)((char*)workspace + (size_t)n * ntiles * WIN * WIN * ACC_C * sizeof(float));
@@ -939,6 +1042,7 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
         epoch = ++g_render_epoch;
         if (epoch == 0) epoch = ++g_render_epoch;  // 0 is what g3_render_workspace_init leaves in the stamps
     }
+    if (h + 2 > 32767 || w + 2 > 65535) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: image too large for the packed texel ids (h < 32766, w < 65534)");
     hipError_t e = hipMemsetAsync(gmax, 0, ((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned), s);
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, cam, maskz, gmax,

@@ -1,0 +1,126 @@
+"""Model of the generalised register merge of warp_splat_windows_kernel: counts what is left for LDS atomics."""
+import numpy as np, sys
+import os; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_render import scene
+h,w=704,1280
+depth,img,K=scene(h,w)
+f=np.float32
+Kinv=np.linalg.inv(K.astype(np.float64)).astype(f)
+ys,xs=np.mgrid[0:h,0:w].astype(f)
+px=(Kinv[0,0]*xs+Kinv[0,1]*ys+Kinv[0,2]).astype(f); py=(Kinv[1,0]*xs+Kinv[1,1]*ys+Kinv[1,2]).astype(f)
+X=(px*depth).astype(f); Y=(py*depth).astype(f); Z=depth
+def geom(tx):
+    cx=(X+f(tx)).astype(f)
+    pr0=((K[0,0]*cx+K[0,1]*Y).astype(f)+K[0,2]*Z).astype(f); pr1=((K[1,0]*cx+K[1,1]*Y).astype(f)+K[1,2]*Z).astype(f)
+    u=(pr0/(Z+f(1e-7))).astype(f); v=(pr1/(Z+f(1e-7))).astype(f)
+    ox=((u-xs).astype(f)+xs+1).astype(f); oy=((v-ys).astype(f)+ys+1).astype(f)
+    cl=lambda a,hi: np.clip(a,0,hi).astype(np.int64)
+    return cl(np.floor(ox),w+1),cl(np.ceil(ox),w+1),cl(np.floor(oy),h+1),cl(np.ceil(oy),h+1)
+def sim_tile(FX,CX,FY,CY,ty0,tx0, general=True):
+    # returns (#store corners, #atomic corners) ; values modelled as 1.0 weights to check conservation
+    tot_atomic=0; tot_store=0
+    contrib={}  # texel -> total (for conservation)
+    final={}
+    owner={}
+    pend=[]  # (tex, val, kind)
+    for wv in range(4):
+        # wave: lanes 0..63 ; thread t = wv*64+lane ; rows ty0 + 4*(t>>5) + k ; col tx0 + (t&31)
+        TW=np.full((64,4,2),-1,np.int64); TE=np.full((64,4,2),-1,np.int64)
+        W=np.zeros((64,4,2)); E=np.zeros((64,4,2))
+        for lane in range(64):
+            t=wv*64+lane
+            for k in range(4):
+                y=ty0+4*(t>>5)+k; x=tx0+(t&31)
+                if y>=h or x>=w: continue
+                fx,cx,fy,cy=FX[y,x],CX[y,x],FY[y,x],CY[y,x]
+                TW[lane,k]=[fy*65536+fx, cy*65536+fx]; TE[lane,k]=[fy*65536+cx, cy*65536+cx]
+                W[lane,k]=[1,1]; E[lane,k]=[1,1]
+                for tx_ in (fy*65536+fx, cy*65536+fx, fy*65536+cx, cy*65536+cx): contrib[tx_]=contrib.get(tx_,0)+1
+        if general:
+            for lane in range(64):
+                for k in range(4):
+                    if TW[lane,k,0]<0: continue
+                    if TW[lane,k,1]==TW[lane,k,0]: W[lane,k,0]+=W[lane,k,1]; TW[lane,k,1]=-1; W[lane,k,1]=0
+                    if TE[lane,k,1]==TE[lane,k,0]: E[lane,k,0]+=E[lane,k,1]; TE[lane,k,1]=-1; E[lane,k,1]=0
+                    for c in range(2):
+                        if TE[lane,k,c]<0: continue
+                        for cc in range(2):
+                            if TW[lane,k,cc]==TE[lane,k,c]: W[lane,k,cc]+=E[lane,k,c]; TE[lane,k,c]=-1; E[lane,k,c]=0; break
+            # horizontal: snapshot donors first (DPP reads pre-merge values of lane-1's EAST corners: east never receives, so fine)
+            taken=np.zeros((64,4,2),bool)
+            for lane in range(64):
+                if lane&31==0: continue
+                for k in range(4):
+                    for c in range(2):
+                        T=TE[lane-1,k,c]
+                        if T<0: continue
+                        done=False
+                        for j in (k,k-1,k+1):
+                            if j<0 or j>3 or done: continue
+                            for cc in range(2):
+                                if TW[lane,j,cc]==T:
+                                    W[lane,j,cc]+=E[lane-1,k,c]; taken[lane-1,k,c]=True; done=True; break
+            for lane in range(64):
+                for k in range(4):
+                    for c in range(2):
+                        if taken[lane,k,c]: TE[lane,k,c]=-1; E[lane,k,c]=0
+            # vertical in thread
+            for lane in range(64):
+                for k in range(3):
+                    for c in range(2):
+                        T=TW[lane,k,c]
+                        if T<0: continue
+                        for cc in range(2):
+                            if TW[lane,k+1,cc]==T: W[lane,k+1,cc]+=W[lane,k,c]; TW[lane,k,c]=-1; W[lane,k,c]=0; break
+            # cross half
+            for lane in range(32,64):
+                for c in range(2):
+                    T=TW[lane-32,3,c]
+                    if T<0: continue
+                    done=False
+                    for j in (0,1):
+                        if done: break
+                        for cc in range(2):
+                            if TW[lane,j,cc]==T: W[lane,j,cc]+=W[lane-32,3,c]; TW[lane-32,3,c]=-1; W[lane-32,3,c]=0; done=True; break
+        else:
+            # current kernel: strict pattern
+            on=TW[:,:,0]>=0
+            FXl=TW[:,:,0]&0xffff; FYl=TW[:,:,0]>>16; CYl=TW[:,:,1]>>16; CXl=TE[:,:,0]&0xffff
+            eg=np.zeros((64,4),bool); swg=np.zeros((64,4),bool)
+            for lane in range(64):
+                if lane&31==0: continue
+                for k in range(4):
+                    if on[lane,k] and on[lane-1,k] and CXl[lane-1,k]==FXl[lane,k] and FYl[lane-1,k]==FYl[lane,k] and CYl[lane-1,k]==CYl[lane,k]:
+                        W[lane,k,0]+=E[lane-1,k,0]; W[lane,k,1]+=E[lane-1,k,1]; eg[lane-1,k]=True
+            for lane in range(64):
+                for k in range(3):
+                    if on[lane,k] and on[lane,k+1] and FXl[lane,k]==FXl[lane,k+1] and CYl[lane,k]==FYl[lane,k+1]:
+                        W[lane,k+1,0]+=W[lane,k,1]; swg[lane,k]=True
+            for lane in range(32,64):
+                if on[lane,0] and on[lane-32,3] and FXl[lane-32,3]==FXl[lane,0] and CYl[lane-32,3]==FYl[lane,0]:
+                    W[lane,0,0]+=W[lane-32,3,1]; swg[lane-32,3]=True
+            for lane in range(64):
+                for k in range(4):
+                    if eg[lane,k]: TE[lane,k]=-1; E[lane,k]=0
+                    if swg[lane,k]: TW[lane,k,1]=-1; W[lane,k,1]=0
+        for lane in range(64):
+            for k in range(4):
+                for c in range(2):
+                    if TW[lane,k,c]>=0: pend.append((TW[lane,k,c],W[lane,k,c],'w' if (general or c==0) else 'a'))
+                    if TE[lane,k,c]>=0: pend.append((TE[lane,k,c],E[lane,k,c],'a'))
+    # owner: last writer among 'w' candidates wins
+    for i,(T,v,kind) in enumerate(pend):
+        if kind=='w': owner[T]=i
+    for i,(T,v,kind) in enumerate(pend):
+        final[T]=final.get(T,0)+v
+        if kind=='w' and owner[T]==i: tot_store+=1
+        else: tot_atomic+=1
+    assert final.keys()==contrib.keys() and all(abs(final[t]-contrib[t])<1e-9 for t in contrib), "conservation"
+    return tot_store,tot_atomic
+for tx in (0.1,0.3):
+    G=geom(tx)
+    for general in (False,True):
+        S=A=0;n=0
+        for (ty0,tx0) in ((0,0),(320,640),(256,352),(480,896),(672,1248),(160,96)):
+            s,a=sim_tile(*G,ty0,tx0,general); S+=s;A+=a;n+=1024
+        print('tx',tx,'general' if general else 'current','stores/pixel %.3f'%(S/n),'atomic corners/pixel %.3f'%(A/n))
