@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                                                                  int group_size, int tiles_x, const int* __restrict__ src_idx = nullptr,
                                                                  unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
-    __shared__ int org[2];
+    __shared__ int org_w[4][2];  // per-wave minima of the destination corners (the window origin is their minimum)
     __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
     const int item = blockIdx.y;
     const int hw = h * w;
@@ -289,7 +289,6 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     float* acc_item = accum + (int64_t)item * (h + 2) * aw * ACC_C;
     const int ty0 = (blockIdx.x / tiles_x) * TS, tx0 = (blockIdx.x % tiles_x) * TS;
     const int64_t slot = (int64_t)item * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0) { org[0] = 0x7fffffff; org[1] = 0x7fffffff; }
     // All 28 loads of the thread's four pixels go out first, unconditionally (an out-of-image pixel reads pixel 0 and is switched off below): with
     // the loads behind `if (mask != 0)` every pixel paid two dependent HBM round trips and a workgroup - LDS holds only four per CU - sat idle
     // through eight of them. The zero fill of the window runs underneath them.
@@ -314,40 +313,6 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         for (int i = threadIdx.x; i < WIN * WIN * ACC_C / 4; i += 256) wz[i] = zero4;
         for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
     }
-    __syncthreads();
-
-    SplatGeom g[4];
-    float wscale[4], col[4][4];  // dw ; r, g, b, z
-    bool on[4];
-    int mnx = 0x7fffffff, mny = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
-        on[k] = inb[k] && mk[k] != 0.f;
-        if (!on[k]) continue;
-        const float z = zin[k];
-        g[k] = splat_geom(flx[k], fly[k], px, py, h, w);
-        const float logd = log1pf(fmaxf(z, 0.f));
-        const float expo = logd / (lmax + 1e-7f) * 50.0f;
-        const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
-        wscale[k] = dw;
-        col[k][0] = rgb[k][0];
-        col[k][1] = rgb[k][1];
-        col[k][2] = rgb[k][2];
-        col[k][3] = z;
-        mnx = min(mnx, g[k].fx);
-        mny = min(mny, g[k].fy);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, o, 64));
-        mny = min(mny, __shfl_xor(mny, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&org[0], mnx); atomicMin(&org[1], mny); }
-    __syncthreads();
-    const int ox = org[0], oy = org[1];
-    if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
-    if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
     // Accumulate into the window. A thread owns 4 consecutive rows of one column; a wave 8 rows x 32 columns (lanes 0..31: rows 8 v .. 8 v + 3,
     // lanes 32..63: rows 8 v + 4 .. 8 v + 7). LDS float atomics are what bounds this kernel (see above: ~6 LDS cycles per LANE), so contributions
     // that meet in one destination texel are summed in registers first and every texel then gets, as far as possible, ONE plain store.
@@ -363,22 +328,30 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     // Every lane runs the cross-lane moves (they would read garbage from lanes masked off by a branch).
     const int lane = threadIdx.x & 63;
     const bool upper = lane >= 32;
-    float Wv[4][2][ACC_C], Ev[4][2][ACC_C];  // [row][0 north / 1 south][r g b z weight]
+    float Wv[4][2][ACC_C];  // west corners [row][0 north / 1 south][r g b z weight]: they receive sums, so all five values are kept
+    float Ew[4][2], colk[4][4];  // east corners stay products of the pixel's (r g b z) and a weight until somebody needs the values
     int tw[4][2], te[4][2];
+    int mnx = 0x7fffffff, mny = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         tw[k][0] = tw[k][1] = te[k][0] = te[k][1] = -1;
-        if (on[k]) {
+        if (inb[k] && mk[k] != 0.f) {
+            const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
+            const float z = zin[k];
+            const SplatGeom gk = splat_geom(flx[k], fly[k], px, py, h, w);
+            const float logd = log1pf(fmaxf(z, 0.f));
+            const float expo = logd / (lmax + 1e-7f) * 50.0f;
+            const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
             const float m = mk[k];
-            const float dw = wscale[k];
-            const float wts[4] = {g[k].nw * m * 1.0f / dw, g[k].sw * m * 1.0f / dw, g[k].ne * m * 1.0f / dw, g[k].se * m * 1.0f / dw};
+            colk[k][0] = rgb[k][0]; colk[k][1] = rgb[k][1]; colk[k][2] = rgb[k][2]; colk[k][3] = z;
+            mnx = min(mnx, gk.fx);
+            mny = min(mny, gk.fy);
+            const float wts[4] = {gk.nw * m * 1.0f / dw, gk.sw * m * 1.0f / dw, gk.ne * m * 1.0f / dw, gk.se * m * 1.0f / dw};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Wv[k][0][e] = col[k][e] * wts[0]; Wv[k][1][e] = col[k][e] * wts[1]; Ev[k][0][e] = col[k][e] * wts[2]; Ev[k][1][e] = col[k][e] * wts[3];
-            }
-            Wv[k][0][4] = wts[0]; Wv[k][1][4] = wts[1]; Ev[k][0][4] = wts[2]; Ev[k][1][4] = wts[3];
-            tw[k][0] = (g[k].fy << 16) | g[k].fx; tw[k][1] = (g[k].cy << 16) | g[k].fx;
-            te[k][0] = (g[k].fy << 16) | g[k].cx; te[k][1] = (g[k].cy << 16) | g[k].cx;
+            for (int e = 0; e < 4; ++e) { Wv[k][0][e] = colk[k][e] * wts[0]; Wv[k][1][e] = colk[k][e] * wts[1]; }
+            Wv[k][0][4] = wts[0]; Wv[k][1][4] = wts[1]; Ew[k][0] = wts[2]; Ew[k][1] = wts[3];
+            tw[k][0] = (gk.fy << 16) | gk.fx; tw[k][1] = (gk.cy << 16) | gk.fx;
+            te[k][0] = (gk.fy << 16) | gk.cx; te[k][1] = (gk.cy << 16) | gk.cx;
             // (1) coinciding corners of this pixel
             if (tw[k][1] == tw[k][0]) {
 #pragma unroll
@@ -386,8 +359,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                 tw[k][1] = -1;
             }
             if (te[k][1] == te[k][0]) {
-#pragma unroll
-                for (int e = 0; e < ACC_C; ++e) Ev[k][0][e] += Ev[k][1][e];
+                Ew[k][0] += Ew[k][1];
                 te[k][1] = -1;
             }
 #pragma unroll
@@ -397,13 +369,17 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                 if (cc < 0) continue;
 #pragma unroll
                 for (int e = 0; e < ACC_C; ++e) {
-                    if (cc == 0) Wv[k][0][e] += Ev[k][c][e]; else Wv[k][1][e] += Ev[k][c][e];
+                    const float v = e < 4 ? colk[k][e < 4 ? e : 0] * Ew[k][c] : Ew[k][c];
+                    if (cc == 0) Wv[k][0][e] += v; else Wv[k][1][e] += v;
                 }
                 te[k][c] = -1;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < ACC_C; ++e) Wv[k][0][e] = Wv[k][1][e] = Ev[k][0][e] = Ev[k][1][e] = 0.f;
+            for (int e = 0; e < ACC_C; ++e) Wv[k][0][e] = Wv[k][1][e] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) colk[k][e] = 0.f;
+            Ew[k][0] = Ew[k][1] = 0.f;
         }
     }
     // (2) east corners of the left neighbour -> my west corners
@@ -411,12 +387,17 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         unsigned mytake = 0;  // bit 2 k + c: I took east corner (k, c) of lane - 1
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            float pcol[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pcol[e] = lane_prev(colk[k][e]);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int p_t = lane_prev(te[k][c]);
+                const float p_w = lane_prev(Ew[k][c]);
                 float pv[ACC_C];
 #pragma unroll
-                for (int e = 0; e < ACC_C; ++e) pv[e] = lane_prev(Ev[k][c][e]);
+                for (int e = 0; e < 4; ++e) pv[e] = pcol[e] * p_w;
+                pv[4] = p_w;
                 const bool can = (lane & 31) != 0 && p_t >= 0;  // lanes 0 / 32 have no left neighbour in their rows
                 bool done = false;
 #pragma unroll
@@ -493,6 +474,19 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                 if ((u_take >> c) & 1u) tw[3][c] = -1;
         }
     }
+    // window origin = minimum north-west corner of the tile (per-wave minima, no initialisation pass and no LDS atomics); the barrier also
+    // closes the zero fill
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, o, 64));
+        mny = min(mny, __shfl_xor(mny, o, 64));
+    }
+    if (lane == 0) { org_w[threadIdx.x >> 6][0] = mnx; org_w[threadIdx.x >> 6][1] = mny; }
+    __syncthreads();
+    const int ox = min(min(org_w[0][0], org_w[1][0]), min(org_w[2][0], org_w[3][0]));
+    const int oy = min(min(org_w[0][1], org_w[1][1]), min(org_w[2][1], org_w[3][1]));
+    if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
+    if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
     // After the merge almost every destination texel receives exactly one value. LDS float atomics cost ~6 LDS cycles per LANE (PMC), plain
     // stores 2 cycles per wave instruction, so the texels are first given an owner: every west corner still alive writes its id to
     // owner[its texel] (last writer wins), and after a barrier the corner that reads its own id back STORES its five values into the
@@ -545,7 +539,10 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (tw[k][c] >= 0) add_texel(tw[k][c], Wv[k][c]);
-            if (te[k][c] >= 0) add_texel(te[k][c], Ev[k][c]);
+            if (te[k][c] >= 0) {
+                const float ev[ACC_C] = {colk[k][0] * Ew[k][c], colk[k][1] * Ew[k][c], colk[k][2] * Ew[k][c], colk[k][3] * Ew[k][c], Ew[k][c]};
+                add_texel(te[k][c], ev);
+            }
         }
     }
     __syncthreads();
