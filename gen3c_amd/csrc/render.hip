@@ -78,6 +78,24 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const float* __restri
     }
 }
 
+// small vector helpers of the mesh-occlusion test (also used by the resolve pass when it applies the occlusion itself)
+struct V3 { float x, y, z; };
+G3_DEVICE V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+G3_DEVICE V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+G3_DEVICE float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+G3_DEVICE V3 pixel_ray(const float* Ki, int px, int py) {  // get_camera_rays: K^-1 [x,y,1], normalised
+    const float xs = (float)px, ys = (float)py;
+    V3 d;
+    d.x = (Ki[0] * xs + Ki[1] * ys) + Ki[2] * 1.0f;
+    d.y = (Ki[3] * xs + Ki[4] * ys) + Ki[5] * 1.0f;
+    d.z = (Ki[6] * xs + Ki[7] * ys) + Ki[8] * 1.0f;
+    float nrm = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
+    if (nrm == 0.f) nrm = 1.f;
+    return {d.x / nrm, d.y / nrm, d.z / nrm};
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // (2) splat
 // ---------------------------------------------------------------------------------------------------------------
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(256) void warp_splat_kernel(const float* __restrict
 // global atomics, so any flow stays correct. Same contributions as the direct kernel; only the (already order-dependent)
 // summation order differs.
 constexpr int TS = 32;    // source tile edge
+constexpr int ORG_N = 4;  // per source tile: window origin (x, y) and used extent (columns, rows); origin x = INT_MAX: nothing in the tile
 constexpr int WIN = 40;   // destination window edge (32 KiB of LDS: 4-5 workgroups per CU; 48: 0.105 vs 0.095 ms per item on the bench scene)
 __global__ __launch_bounds__(256) void warp_splat_tiled_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
                                                                const float* __restrict__ flow, const float* __restrict__ maskz,
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                                                                  int group_size, int tiles_x, const int* __restrict__ src_idx = nullptr,
                                                                  unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
-    __shared__ int org_w[4][2];  // per-wave minima of the destination corners (the window origin is their minimum)
+    __shared__ int org_w[4][4];  // per-wave minima of the north-west / maxima of the south-east destination corners: window origin and extent
     __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
     const int item = blockIdx.y;
     const int hw = h * w;
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     float Wv[4][2][ACC_C];  // west corners [row][0 north / 1 south][r g b z weight]: they receive sums, so all five values are kept
     float Ew[4][2], colk[4][4];  // east corners stay products of the pixel's (r g b z) and a weight until somebody needs the values
     int tw[4][2], te[4][2];
-    int mnx = 0x7fffffff, mny = 0x7fffffff;
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         tw[k][0] = tw[k][1] = te[k][0] = te[k][1] = -1;
@@ -346,6 +365,8 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
             colk[k][0] = rgb[k][0]; colk[k][1] = rgb[k][1]; colk[k][2] = rgb[k][2]; colk[k][3] = z;
             mnx = min(mnx, gk.fx);
             mny = min(mny, gk.fy);
+            mxx = max(mxx, gk.cx);
+            mxy = max(mxy, gk.cy);
             const float wts[4] = {gk.nw * m * 1.0f / dw, gk.sw * m * 1.0f / dw, gk.ne * m * 1.0f / dw, gk.se * m * 1.0f / dw};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Wv[k][0][e] = colk[k][e] * wts[0]; Wv[k][1][e] = colk[k][e] * wts[1]; }
@@ -480,12 +501,18 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     for (int o = 32; o > 0; o >>= 1) {
         mnx = min(mnx, __shfl_xor(mnx, o, 64));
         mny = min(mny, __shfl_xor(mny, o, 64));
+        mxx = max(mxx, __shfl_xor(mxx, o, 64));
+        mxy = max(mxy, __shfl_xor(mxy, o, 64));
     }
-    if (lane == 0) { org_w[threadIdx.x >> 6][0] = mnx; org_w[threadIdx.x >> 6][1] = mny; }
+    if (lane == 0) { int* ow = org_w[threadIdx.x >> 6]; ow[0] = mnx; ow[1] = mny; ow[2] = mxx; ow[3] = mxy; }
     __syncthreads();
     const int ox = min(min(org_w[0][0], org_w[1][0]), min(org_w[2][0], org_w[3][0]));
     const int oy = min(min(org_w[0][1], org_w[1][1]), min(org_w[2][1], org_w[3][1]));
-    if (threadIdx.x == 0) { origins[2 * slot] = ox; origins[2 * slot + 1] = oy; }
+    // used part of the window: only its rows are written out below and only its texels are read by the gather (a smooth flow fills ~34 x 34 of
+    // the 40 x 40 texels)
+    const int ex = min(WIN, max(max(org_w[0][2], org_w[1][2]), max(org_w[2][2], org_w[3][2])) - ox + 1);
+    const int ey = min(WIN, max(max(org_w[0][3], org_w[1][3]), max(org_w[2][3], org_w[3][3])) - oy + 1);
+    if (threadIdx.x == 0) { int* og = origins + ORG_N * slot; og[0] = ox; og[1] = oy; og[2] = ex; og[3] = ey; }
     if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
     // After the merge almost every destination texel receives exactly one value. LDS float atomics cost ~6 LDS cycles per LANE (PMC), plain
     // stores 2 cycles per wave instruction, so the texels are first given an owner: every west corner still alive writes its id to
@@ -548,15 +575,16 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     __syncthreads();
     f32x4* dst = reinterpret_cast<f32x4*>(windows + slot * (WIN * WIN * ACC_C));
     const f32x4* src = reinterpret_cast<const f32x4*>(win);
-    for (int i = threadIdx.x; i < WIN * WIN * ACC_C / 4; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < ey * (WIN * ACC_C / 4); i += 256) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* __restrict__ windows, const int* __restrict__ origins,
                                                                   float* __restrict__ accum, float* __restrict__ frame,
                                                                   float* __restrict__ mask, float* __restrict__ depth, int n, int h, int w,
                                                                   int ntiles, int tiles_x, const unsigned* __restrict__ dirty = nullptr,
-                                                                  unsigned epoch = 0) {
-    __shared__ int lst[256 * 3];  // overlapping source tiles of one scan chunk: tile, ox, oy
+                                                                  unsigned epoch = 0, const unsigned* __restrict__ tmin = nullptr,
+                                                                  const float* __restrict__ Kinv = nullptr) {
+    __shared__ int lst[256 * 5];  // overlapping source tiles of one scan chunk: tile, ox, oy, ex, ey
     __shared__ int wave_cnt[4];
     const int item = blockIdx.y;
     const int hw = h * w;
@@ -567,7 +595,7 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
     // Otherwise (g3_render_items_f32) the accumulator is all zero except for items the splat kernel stamped with this launch's epoch: only those
     // read it (20 bytes per pixel saved on the common path) and put the zeros back, so the buffer never needs a clearing pass.
     const bool read_acc = dirty == nullptr || dirty[item] == epoch;
-    const int* org_item = origins + (int64_t)item * ntiles * 2;
+    const int* org_item = origins + (int64_t)item * ntiles * ORG_N;
     const float* win_item = windows + (int64_t)item * ntiles * (WIN * WIN * ACC_C);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
@@ -594,10 +622,13 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
     }
     for (int base = 0; base < ntiles; base += 256) {
         const int t = base + threadIdx.x;
-        int ox = 0x7fffffff, oy = 0x7fffffff;
-        if (t < ntiles) { ox = org_item[2 * t]; oy = org_item[2 * t + 1]; }
-        // window texels [oy, oy + WIN) x [ox, ox + WIN) against this tile's texels [dy0 + 1, dy0 + TS] x [dx0 + 1, dx0 + TS]
-        const bool hit = ox != 0x7fffffff && ox <= dx0 + TS && ox + WIN > dx0 + 1 && oy <= dy0 + TS && oy + WIN > dy0 + 1;
+        int ox = 0x7fffffff, oy = 0x7fffffff, ex = 0, ey = 0;
+        if (t < ntiles) {
+            const int4 og = *reinterpret_cast<const int4*>(org_item + ORG_N * t);
+            ox = og.x; oy = og.y; ex = og.z; ey = og.w;
+        }
+        // used window texels [oy, oy + ey) x [ox, ox + ex) against this tile's texels [dy0 + 1, dy0 + TS] x [dx0 + 1, dx0 + TS]
+        const bool hit = ox != 0x7fffffff && ox <= dx0 + TS && ox + ex > dx0 + 1 && oy <= dy0 + TS && oy + ey > dy0 + 1;
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) wave_cnt[wv] = __popcll(bal);
         __syncthreads();
@@ -609,16 +640,17 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
         }
         if (hit) {
             const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));  // ascending tile order: the summation order below is fixed
-            lst[3 * pos] = t; lst[3 * pos + 1] = ox; lst[3 * pos + 2] = oy;
+            int* l = lst + 5 * pos;
+            l[0] = t; l[1] = ox; l[2] = oy; l[3] = ex; l[4] = ey;
         }
         __syncthreads();
         for (int i = 0; i < total; ++i) {
-            const int tt = lst[3 * i], tox = lst[3 * i + 1], toy = lst[3 * i + 2];
+            const int tt = lst[5 * i], tox = lst[5 * i + 1], toy = lst[5 * i + 2], tex = lst[5 * i + 3], tey = lst[5 * i + 4];
             const float* wb = win_item + (int64_t)tt * (WIN * WIN * ACC_C);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int lx = gx[k] - tox, ly = gy[k] - toy;
-                if (inb[k] && (unsigned)lx < (unsigned)WIN && (unsigned)ly < (unsigned)WIN) {
+                if (inb[k] && (unsigned)lx < (unsigned)tex && (unsigned)ly < (unsigned)tey) {
                     const float* a = wb + (ly * WIN + lx) * ACC_C;
 #pragma unroll
                     for (int e = 0; e < ACC_C; ++e) sum[k][e] += a[e];
@@ -634,14 +666,26 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
         float wt = sum[k][4];
         if (wt != wt) wt = 1000.0f;  // nan_to_num(nan=1000)
         const bool ok = wt > 0.f;
+        const float dval = ok ? sum[k][3] / wt : 0.0f;
+        // mesh occlusion applied here when the rasteriser ran before this pass (g3_render_items_f32): the arithmetic of mesh_apply_kernel on the
+        // values this thread is about to write, instead of a separate read-modify-write pass over frame / mask / depth
+        float keep = 1.0f;
+        if (tmin) {
+            const unsigned bits = tmin[(int64_t)item * hw + pix];
+            const float t = (bits == 0x7f800000u) ? 0.f : __uint_as_float(bits);
+            const V3 d = pixel_ray(Kinv + item * 9, gx[k] - 1, gy[k] - 1);
+            const float mesh_z = t * d.z;
+            keep = (((mesh_z + 0.02f) < dval) && (mesh_z > 0.f)) ? 0.f : 1.f;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = ok ? sum[k][c] / wt : -1.0f;
             v = fminf(fmaxf(v, -1.0f), 1.0f);
+            if (tmin) v = (v + 1.0f) * keep - 1.0f;
             frame[((int64_t)item * 3 + c) * hw + pix] = v;
         }
-        mask[(int64_t)item * hw + pix] = ok ? 1.0f : 0.0f;
-        if (depth) depth[(int64_t)item * hw + pix] = ok ? sum[k][3] / wt : 0.0f;
+        mask[(int64_t)item * hw + pix] = tmin ? (ok ? 1.0f : 0.0f) * keep : (ok ? 1.0f : 0.0f);
+        if (depth) depth[(int64_t)item * hw + pix] = tmin ? dval * keep : dval;
     }
 }
 
@@ -684,11 +728,22 @@ G3_DEVICE void bilinear_src(int i, float scale, int n_in, int& i0, int& i1, floa
     l0 = 1.0f - l1;
 }
 
+// cam == nullptr (g3_render_items_f32): the camera-space points are recomputed from the cached world points with warp_project_kernel's
+// expression (same operation order, so the same bits) - only ~1/4 of the pixels are sampled, and the projection then has no 12-byte-per-pixel
+// cam buffer to write.
 __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __restrict__ cam, const uint8_t* __restrict__ bmask,
                                                               float* __restrict__ pts, uint8_t* __restrict__ m, int n, int h,
-                                                              int w, int nh, int nw, const int* __restrict__ src = nullptr) {
+                                                              int w, int nh, int nw, const int* __restrict__ src = nullptr,
+                                                              const float* __restrict__ points = nullptr, const float* __restrict__ w2c = nullptr) {
     const int item = blockIdx.y;
     const int sitem = src ? src[item] : item;
+    const float* W = w2c ? w2c + item * 16 : nullptr;
+    const float* psrc = points ? points + (int64_t)sitem * h * w * 3 : nullptr;
+    auto cam_at = [&](int y, int x, int k) -> float {
+        if (cam) return cam[((int64_t)item * h * w + (int64_t)y * w + x) * 3 + k];
+        const float* p = psrc + ((int64_t)y * w + x) * 3;
+        return ((W[k * 4 + 0] * p[0] + W[k * 4 + 1] * p[1]) + W[k * 4 + 2] * p[2]) + W[k * 4 + 3] * 1.0f;
+    };
     const float sy = (float)h / (float)nh, sx = (float)w / (float)nw;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nh * nw; idx += gridDim.x * 256) {
         const int i = idx / nw, j = idx - i * nw;
@@ -696,11 +751,10 @@ __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __res
         float wy0, wy1, wx0, wx1;
         bilinear_src(i, sy, h, y0, y1, wy0, wy1);
         bilinear_src(j, sx, w, x0, x1, wx0, wx1);
-        const float* c = cam + (int64_t)item * h * w * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float top = c[((int64_t)y0 * w + x0) * 3 + k] * wx0 + c[((int64_t)y0 * w + x1) * 3 + k] * wx1;
-            const float bot = c[((int64_t)y1 * w + x0) * 3 + k] * wx0 + c[((int64_t)y1 * w + x1) * 3 + k] * wx1;
+            const float top = cam_at(y0, x0, k) * wx0 + cam_at(y0, x1, k) * wx1;
+            const float bot = cam_at(y1, x0, k) * wx0 + cam_at(y1, x1, k) * wx1;
             pts[((int64_t)item * nh * nw + idx) * 3 + k] = top * wy0 + bot * wy1;
         }
         const int my = (int)floorf((float)i * sy), mx = (int)floorf((float)j * sx);
@@ -708,80 +762,163 @@ __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __res
     }
 }
 
-struct V3 { float x, y, z; };
-G3_DEVICE V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-G3_DEVICE V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-G3_DEVICE float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-
-G3_DEVICE V3 pixel_ray(const float* Ki, int px, int py) {  // get_camera_rays: K^-1 [x,y,1], normalised
-    const float xs = (float)px, ys = (float)py;
-    V3 d;
-    d.x = (Ki[0] * xs + Ki[1] * ys) + Ki[2] * 1.0f;
-    d.y = (Ki[3] * xs + Ki[4] * ys) + Ki[5] * 1.0f;
-    d.z = (Ki[6] * xs + Ki[7] * ys) + Ki[8] * 1.0f;
-    float nrm = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z);
-    if (nrm == 0.f) nrm = 1.f;
-    return {d.x / nrm, d.y / nrm, d.z / nrm};
+// Moller-Trumbore for the ray through pixel (px, py) and one triangle given as (e1, e2, s = -v0, q = s x e1, e2q = e2 . q): the branch order
+// and epsilons of ray_triangle_intersection_warp.py:23-105; min-t is an atomicMin on the float bit pattern (t > 0: uint order == float order).
+// per-item counters of the mesh pass live CNT_STRIDE ints apart: counters of different items in ONE cache line serialise in the L2 (32 items x
+// ~300 wave atomics on one line: 95 us for a pass that otherwise takes 5)
+constexpr int CNT_STRIDE = 32;
+struct TriSetup { V3 e1, e2, s, q; float e2q; };
+G3_DEVICE TriSetup tri_setup(V3 v0, V3 v1, V3 v2) {
+    TriSetup t;
+    t.e1 = sub(v1, v0); t.e2 = sub(v2, v0);
+    t.s = {0.f - v0.x, 0.f - v0.y, 0.f - v0.z};  // ray origin (0) - v0
+    t.q = cross(t.s, t.e1);
+    t.e2q = dot(t.e2, t.q);
+    return t;
+}
+G3_DEVICE void ray_tri_min(const TriSetup& T, V3 d, float eps, unsigned* __restrict__ out_px) {
+    const V3 hh = cross(d, T.e2);
+    const float a = dot(T.e1, hh);
+    if (fabsf(a) < eps) return;
+    const float f = 1.0f / a;
+    const float u = f * dot(T.s, hh);
+    if (u < 0.f || u > 1.f) return;
+    const float v = f * dot(d, T.q);
+    if (v < 0.f || (u + v) > 1.f) return;
+    const float t = f * T.e2q;
+    // values only ever decrease, so a (possibly stale) read that is already <= t makes the atomic redundant; overlapping skirt triangles
+    // cover most pixels several times
+    if (t > eps && __float_as_uint(t) < *(volatile unsigned*)out_px) atomicMin(out_px, __float_as_uint(t));
+}
+G3_DEVICE void patch_triangle(const float* __restrict__ P, int nw, int patch, int tri, V3& v0, V3& v1, V3& v2) {
+    const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
+    auto vert = [&](int i, int j) -> V3 { const float* p = P + ((int64_t)i * nw + j) * 3; return {p[0], p[1], p[2]}; };
+    // points_to_mesh: (tl, tr, bl) and (tr, br, bl)
+    v0 = tri == 0 ? vert(pi, pj) : vert(pi, pj + 1);
+    v1 = tri == 0 ? vert(pi, pj + 1) : vert(pi + 1, pj + 1);
+    v2 = vert(pi + 1, pj);
 }
 
-// one wave per mesh patch; lanes sweep the pixel bounding box of each of its two triangles
-__global__ __launch_bounds__(256) void mesh_raster_kernel(const float* __restrict__ pts, const uint8_t* __restrict__ m,
-                                                          const float* __restrict__ Kmat, const float* __restrict__ Kinv,
-                                                          unsigned* __restrict__ tmin, int n, int h, int w, int nh, int nw,
-                                                          float eps) {
-    const int item = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int patch = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int npatch = (nh - 1) * (nw - 1);
-    if (patch >= npatch) return;
-    const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
-    const uint8_t* mi = m + (int64_t)item * nh * nw;
-    if (!(mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1])) return;
+// The lanes of a wave sweep the conservative pixel bounding box of one triangle (tri = 0 / 1 of a mesh patch). A triangle that touches the
+// camera plane has no finite projection: its box is the whole image. `heavy` == nullptr: swept here all the same (one wave, h * w / 64 rounds);
+// otherwise it is appended to the item's heavy list and mesh_raster_heavy_kernel spreads its pixels over the chip.
+G3_DEVICE void mesh_raster_tri(int item, int patch, int tri, int lane, const float* __restrict__ pts, const float* __restrict__ Kmat,
+                               const float* __restrict__ Kinv, unsigned* __restrict__ tmin, int h, int w, int nh, int nw, float eps,
+                               int* __restrict__ heavy_cnt, int* __restrict__ heavy, int heavy_cap) {
     const float* P = pts + (int64_t)item * nh * nw * 3;
-    auto vert = [&](int i, int j) -> V3 { const float* p = P + ((int64_t)i * nw + j) * 3; return {p[0], p[1], p[2]}; };
-    const V3 tl = vert(pi, pj), tr = vert(pi, pj + 1), bl = vert(pi + 1, pj), br = vert(pi + 1, pj + 1);
     const float* K = Kmat + item * 9;
     const float* Ki = Kinv + item * 9;
     unsigned* out = tmin + (int64_t)item * h * w;
-    for (int tri = 0; tri < 2; ++tri) {
-        const V3 v0 = tri == 0 ? tl : tr, v1 = tri == 0 ? tr : br, v2 = bl;
-        // conservative pixel bounding box of the projected triangle (whole image if it touches the camera plane)
-        int x_lo = 0, x_hi = w - 1, y_lo = 0, y_hi = h - 1;
-        if (v0.z > 1e-4f && v1.z > 1e-4f && v2.z > 1e-4f) {
-            float minx = 3e38f, maxx = -3e38f, miny = 3e38f, maxy = -3e38f;
-            const V3 vs[3] = {v0, v1, v2};
+    V3 v0, v1, v2;
+    patch_triangle(P, nw, patch, tri, v0, v1, v2);
+    int x_lo = 0, x_hi = w - 1, y_lo = 0, y_hi = h - 1;
+    if (v0.z > 1e-4f && v1.z > 1e-4f && v2.z > 1e-4f) {
+        float minx = 3e38f, maxx = -3e38f, miny = 3e38f, maxy = -3e38f;
+        const V3 vs[3] = {v0, v1, v2};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float X = (K[0] * vs[k].x + K[1] * vs[k].y + K[2] * vs[k].z) / vs[k].z;
-                const float Y = (K[3] * vs[k].x + K[4] * vs[k].y + K[5] * vs[k].z) / vs[k].z;
-                minx = fminf(minx, X); maxx = fmaxf(maxx, X); miny = fminf(miny, Y); maxy = fmaxf(maxy, Y);
-            }
-            if (!(maxx >= -2.f && minx <= (float)w + 1.f && maxy >= -2.f && miny <= (float)h + 1.f)) continue;  // off-screen
-            x_lo = max(0, (int)floorf(fmaxf(minx, -2.f)) - 1);
-            y_lo = max(0, (int)floorf(fmaxf(miny, -2.f)) - 1);
-            x_hi = min(w - 1, (int)ceilf(fminf(maxx, (float)w + 1.f)) + 1);
-            y_hi = min(h - 1, (int)ceilf(fminf(maxy, (float)h + 1.f)) + 1);
-            if (x_hi < x_lo || y_hi < y_lo) continue;
+        for (int k = 0; k < 3; ++k) {
+            const float X = (K[0] * vs[k].x + K[1] * vs[k].y + K[2] * vs[k].z) / vs[k].z;
+            const float Y = (K[3] * vs[k].x + K[4] * vs[k].y + K[5] * vs[k].z) / vs[k].z;
+            minx = fminf(minx, X); maxx = fmaxf(maxx, X); miny = fminf(miny, Y); maxy = fmaxf(maxy, Y);
         }
-        const V3 e1 = sub(v1, v0), e2 = sub(v2, v0);
-        const V3 s = {0.f - v0.x, 0.f - v0.y, 0.f - v0.z};  // ray origin (0) - v0
-        const V3 q = cross(s, e1);
-        const float e2q = dot(e2, q);
-        const int bw = x_hi - x_lo + 1;
-        const int npix = bw * (y_hi - y_lo + 1);
-        for (int k = lane; k < npix; k += 64) {
-            const int py = y_lo + k / bw, px = x_lo + k % bw;
-            const V3 d = pixel_ray(Ki, px, py);
-            const V3 hh = cross(d, e2);
-            const float a = dot(e1, hh);
-            if (fabsf(a) < eps) continue;
-            const float f = 1.0f / a;
-            const float u = f * dot(s, hh);
-            if (u < 0.f || u > 1.f) continue;
-            const float v = f * dot(d, q);
-            if (v < 0.f || (u + v) > 1.f) continue;
-            const float t = f * e2q;
-            if (t > eps) atomicMin(out + (int64_t)py * w + px, __float_as_uint(t));  // t > 0: uint order == float order
+        if (!(maxx >= -2.f && minx <= (float)w + 1.f && maxy >= -2.f && miny <= (float)h + 1.f)) return;  // off-screen
+        x_lo = max(0, (int)floorf(fmaxf(minx, -2.f)) - 1);
+        y_lo = max(0, (int)floorf(fmaxf(miny, -2.f)) - 1);
+        x_hi = min(w - 1, (int)ceilf(fminf(maxx, (float)w + 1.f)) + 1);
+        y_hi = min(h - 1, (int)ceilf(fminf(maxy, (float)h + 1.f)) + 1);
+        if (x_hi < x_lo || y_hi < y_lo) return;
+    } else if (heavy) {
+        if (lane == 0) {
+            const int at = atomicAdd(heavy_cnt + item * CNT_STRIDE, 1);
+            if (at < heavy_cap) heavy[(int64_t)item * heavy_cap + at] = patch * 2 + tri;
+        }
+        return;
+    }
+    const TriSetup T = tri_setup(v0, v1, v2);
+    const int bw = x_hi - x_lo + 1;
+    const int npix = bw * (y_hi - y_lo + 1);
+    for (int k = lane; k < npix; k += 64) {
+        const int py = y_lo + k / bw, px = x_lo + k % bw;
+        ray_tri_min(T, pixel_ray(Ki, px, py), eps, out + (int64_t)py * w + px);
+    }
+}
+
+// one wave per mesh patch (g3_mesh_occlusion_f32: no workspace for a heavy list)
+__global__ __launch_bounds__(256) void mesh_raster_wave_kernel(const float* __restrict__ pts, const uint8_t* __restrict__ m,
+                                                               const float* __restrict__ Kmat, const float* __restrict__ Kinv,
+                                                               unsigned* __restrict__ tmin, int n, int h, int w, int nh, int nw,
+                                                               float eps) {
+    const int item = blockIdx.y;
+    const int patch = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (patch >= (nh - 1) * (nw - 1)) return;
+    const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
+    const uint8_t* mi = m + (int64_t)item * nh * nw;
+    if (!(mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1])) return;
+    for (int tri = 0; tri < 2; ++tri) mesh_raster_tri(item, patch, tri, threadIdx.x & 63, pts, Kmat, Kinv, tmin, h, w, nh, nw, eps, nullptr, nullptr, 0);
+}
+
+// g3_render_items_f32: a THREAD per mesh patch tests the boundary mask and the patches that pass are appended to the item's list (one atomic
+// per wave); mesh_raster_list_kernel then gives every listed TRIANGLE to a wave, grid-stride. One wave per patch of the mesh is 1.8 M waves per
+// 32 items of 704 x 1280 of which ~2 % have a boundary patch, and those sit next to each other (the disc outlines), i.e. in few workgroups.
+__global__ __launch_bounds__(256) void mesh_mark_kernel(const uint8_t* __restrict__ m, int* __restrict__ list_cnt, int* __restrict__ list, int list_cap,
+                                                        int n, int nh, int nw) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int npatch = (nh - 1) * (nw - 1);
+    const int mine = blockIdx.x * 256 + threadIdx.x;
+    bool boundary = false;
+    if (mine < npatch) {
+        const int pi = mine / (nw - 1), pj = mine - pi * (nw - 1);
+        const uint8_t* mi = m + (int64_t)item * nh * nw;
+        boundary = (mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1]) != 0;
+    }
+    const unsigned long long bal = __ballot(boundary);
+    if (bal == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(list_cnt + item * CNT_STRIDE, __popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (boundary) {
+        const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (at < list_cap) list[(int64_t)item * list_cap + at] = mine;
+    }
+}
+
+__global__ __launch_bounds__(256) void mesh_raster_list_kernel(const float* __restrict__ pts, const float* __restrict__ Kmat,
+                                                               const float* __restrict__ Kinv, unsigned* __restrict__ tmin,
+                                                               const int* __restrict__ list_cnt, const int* __restrict__ list, int list_cap, int n,
+                                                               int h, int w, int nh, int nw, float eps, int* __restrict__ heavy_cnt,
+                                                               int* __restrict__ heavy, int heavy_cap) {
+    const int item = blockIdx.y;
+    const int ntri = 2 * min(list_cnt[item * CNT_STRIDE], list_cap);
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < ntri; e += gridDim.x * 4)
+        mesh_raster_tri(item, list[(int64_t)item * list_cap + (e >> 1)], e & 1, threadIdx.x & 63, pts, Kmat, Kinv, tmin, h, w, nh, nw, eps, heavy_cnt, heavy,
+                        heavy_cap);
+}
+
+// Triangles on the heavy list against every pixel: a thread owns HEAVY_PX pixels (ray computed once per pixel), the triangles are the inner,
+// wave-uniform loop. Nothing listed (the normal case): the workgroups leave at once.
+constexpr int HEAVY_PX = 8;
+__global__ __launch_bounds__(256) void mesh_raster_heavy_kernel(const float* __restrict__ pts, const float* __restrict__ Kinv,
+                                                                unsigned* __restrict__ tmin, const int* __restrict__ heavy_cnt,
+                                                                const int* __restrict__ heavy, int heavy_cap, int n, int h, int w, int nh,
+                                                                int nw, float eps) {
+    const int item = blockIdx.y;
+    const int cnt = min(heavy_cnt[item * CNT_STRIDE], heavy_cap);
+    if (cnt == 0) return;
+    const float* P = pts + (int64_t)item * nh * nw * 3;
+    const float* Ki = Kinv + item * 9;
+    unsigned* out = tmin + (int64_t)item * h * w;
+    const int hw = h * w;
+    for (int r = 0; r < HEAVY_PX; ++r) {
+        const int pix = (blockIdx.x * HEAVY_PX + r) * 256 + threadIdx.x;
+        if (pix >= hw) break;
+        const int py = pix / w, px = pix - py * w;
+        const V3 d = pixel_ray(Ki, px, py);
+        for (int i = 0; i < cnt; ++i) {
+            const int e = heavy[(int64_t)item * heavy_cap + i];
+            V3 v0, v1, v2;
+            patch_triangle(P, nw, e >> 1, e & 1, v0, v1, v2);
+            ray_tri_min(tri_setup(v0, v1, v2), d, eps, out + pix);
         }
     }
 }
@@ -905,7 +1042,7 @@ extern "C" int g3_warp_resolve_f32(const float* accum, float* frame, float* mask
 extern "C" size_t g3_warp_windows_workspace_bytes(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     const size_t ntiles = (size_t)((w + TS - 1) / TS) * ((h + TS - 1) / TS);
-    return (size_t)n * ntiles * ((size_t)WIN * WIN * ACC_C * sizeof(float) + 2 * sizeof(int));
+    return (size_t)n * ntiles * ((size_t)WIN * WIN * ACC_C * sizeof(float) + ORG_N * sizeof(int));
 }
 
 // splat + resolve without global atomics on the common path (warp_splat_windows_kernel / warp_gather_resolve_kernel above). `accum` as for
@@ -941,7 +1078,7 @@ extern "C" int g3_mesh_occlusion_f32(const float* cam_points, const uint8_t* bou
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_mesh_occlusion_f32: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, cam_points, boundary_mask, pts_ds, mask_ds, n, h, w, nh, nw);
     const int npatch = (nh - 1) * (nw - 1);
-    hipLaunchKernelGGL(mesh_raster_kernel, dim3((npatch + 3) / 4, n), dim3(256), 0, s, pts_ds, mask_ds, K, Kinv, (unsigned*)tmin, n, h, w, nh, nw, 1e-8f);
+    hipLaunchKernelGGL(mesh_raster_wave_kernel, dim3((npatch + 3) / 4, n), dim3(256), 0, s, pts_ds, mask_ds, K, Kinv, (unsigned*)tmin, n, h, w, nh, nw, 1e-8f);
     hipLaunchKernelGGL(mesh_apply_kernel, dim3(grid_x(h * w), n), dim3(256), 0, s, (const unsigned*)tmin, Kinv, frame, mask, depth, n, h, w);
     return g3_check_launch("g3_mesh_occlusion_f32");
 }
@@ -968,7 +1105,7 @@ extern "C" int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int 
  * replicated, and project -> window splat -> gather / resolve -> (mesh occlusion) run back to back on one workspace. */
 namespace {
 struct RenderWs {
-    size_t z, flow, maskz, cam, gmax, accum, windows, origins, dirty, pts_ds, m_ds, tmin, total;
+    size_t z, flow, maskz, gmax, accum, windows, origins, dirty, pts_ds, m_ds, tmin, heavy_cnt, heavy, list, total;
 };
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
@@ -983,13 +1120,15 @@ RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
     L.z = take(n * hw * sizeof(float));
     L.flow = take(n * hw * 2 * sizeof(float));
     L.maskz = take(n * hw * sizeof(float));
-    L.cam = take(n * hw * 3 * sizeof(float));
     L.gmax = take(((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned));
     L.windows = take((size_t)n * ntiles * WIN * WIN * ACC_C * sizeof(float));
-    L.origins = take((size_t)n * ntiles * 2 * sizeof(int));
+    L.origins = take((size_t)n * ntiles * ORG_N * sizeof(int));
     L.pts_ds = take((size_t)n * nh * nw * 3 * sizeof(float));
     L.m_ds = take((size_t)n * nh * nw);
     L.tmin = take(n * hw * sizeof(unsigned));
+    L.heavy_cnt = take((size_t)n * CNT_STRIDE * sizeof(int));  // per item, a 128-byte line of its own: [0] heavy triangles, [1] listed boundary patches
+    L.heavy = take((nh > 1 && nw > 1) ? (size_t)n * (nh - 1) * (nw - 1) * 2 * sizeof(int) : 0);  // every triangle of the mesh could touch the camera plane
+    L.list = take((nh > 1 && nw > 1) ? (size_t)n * (nh - 1) * (nw - 1) * sizeof(int) : 0);
     L.total = o;
     return L;
 }
@@ -1026,7 +1165,6 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     float* z = (float*)(ws + L.z);
     float* flow = flow_out ? flow_out : (float*)(ws + L.flow);
     float* maskz = (float*)(ws + L.maskz);
-    float* cam = boundary_src ? (float*)(ws + L.cam) : nullptr;
     unsigned* gmax = (unsigned*)(ws + L.gmax);
     float* accum = (float*)(ws + L.accum);
     float* windows = (float*)(ws + L.windows);
@@ -1042,26 +1180,35 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     if (h + 2 > 32767 || w + 2 > 65535) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: image too large for the packed texel ids (h < 32766, w < 65534)");
     hipError_t e = hipMemsetAsync(gmax, 0, ((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned), s);
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, cam, maskz, gmax,
-                       n, h, w, group_size, src_index);
-    const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
-                       (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
-    hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
-                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch);
+    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
+                       gmax, n, h, w, group_size, src_index);
+    // mesh occlusion: downsampled mesh of the boundary patches -> per-pixel nearest hit (tmin); the resolve pass below applies it
+    unsigned* tmin = nullptr;
     if (boundary_src) {
         const int nh = h / factor, nw = w / factor;
         float* pts_ds = (float*)(ws + L.pts_ds);
         uint8_t* m_ds = (uint8_t*)(ws + L.m_ds);
-        unsigned* tmin = (unsigned*)(ws + L.tmin);
-        e = hipMemsetD32Async((hipDeviceptr_t)tmin, 0x7f800000, (size_t)n * h * w, s);  // +inf bit pattern
-        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, (const float*)cam, boundary_src, pts_ds, m_ds, n, h, w, nh, nw,
-                           src_index);
+        int* heavy_cnt = (int*)(ws + L.heavy_cnt);
+        int* list_cnt = heavy_cnt + 1;
+        int* heavy = (int*)(ws + L.heavy);
+        int* list = (int*)(ws + L.list);
+        tmin = (unsigned*)(ws + L.tmin);
         const int npatch = (nh - 1) * (nw - 1);
-        hipLaunchKernelGGL(mesh_raster_kernel, dim3((npatch + 3) / 4, n), dim3(256), 0, s, (const float*)pts_ds, (const uint8_t*)m_ds, K, Kinv, tmin, n, h, w, nh,
-                           nw, 1e-8f);
-        hipLaunchKernelGGL(mesh_apply_kernel, dim3(grid_x(h * w), n), dim3(256), 0, s, (const unsigned*)tmin, Kinv, frame, mask, depth, n, h, w);
+        e = hipMemsetD32Async((hipDeviceptr_t)tmin, 0x7f800000, (size_t)n * h * w, s);  // +inf bit pattern
+        if (e == hipSuccess) e = hipMemsetAsync(heavy_cnt, 0, (size_t)n * CNT_STRIDE * sizeof(int), s);
+        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, (const float*)nullptr, boundary_src, pts_ds, m_ds, n, h, w, nh,
+                           nw, src_index, points_src, w2c);
+        hipLaunchKernelGGL(mesh_mark_kernel, dim3((npatch + 255) / 256, n), dim3(256), 0, s, (const uint8_t*)m_ds, list_cnt, list, npatch, n, nh, nw);
+        hipLaunchKernelGGL(mesh_raster_list_kernel, dim3(256, n), dim3(256), 0, s, (const float*)pts_ds, K, Kinv, tmin, (const int*)list_cnt, (const int*)list,
+                           npatch, n, h, w, nh, nw, 1e-8f, heavy_cnt, heavy, npatch * 2);
+        hipLaunchKernelGGL(mesh_raster_heavy_kernel, dim3((h * w + 256 * HEAVY_PX - 1) / (256 * HEAVY_PX), n), dim3(256), 0, s, (const float*)pts_ds, Kinv, tmin,
+                           (const int*)heavy_cnt, (const int*)heavy, npatch * 2, n, h, w, nh, nw, 1e-8f);
     }
+    const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
+                       (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
+    hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
+                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, (const unsigned*)tmin, Kinv);
     return g3_check_launch("g3_render_items_f32");
 }

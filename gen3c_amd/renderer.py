@@ -34,6 +34,11 @@ def _p(t: Optional[torch.Tensor], name: str, dtype=f32) -> int:
     return t.data_ptr()
 
 
+def _tensor_version(t: torch.Tensor) -> int:
+    """In-place version counter for cache keys; inference tensors do not track one (and cannot be edited in place outside inference mode)."""
+    return -1 if t.is_inference() else t._version
+
+
 def _host_inverse(m: torch.Tensor) -> torch.Tensor:
     """inverse_with_conversion (forward_warp_utils_pytorch.py:147-148) on the host, result back on m's device."""
     return torch.linalg.inv(m.detach().to("cpu", f32)).to(m.device)
@@ -251,21 +256,45 @@ class Cache3D_Base:
             return (None if render_depth else frames), masks, (depths if render_depth else None)
         Fs = self.input_image[:, start_frame_idx:start_frame_idx + Ft].shape[1]
         assert Fs in (1, Ft), f"the cache holds {Fs} source frames for {Ft} target frames"
-        b_i = torch.arange(B, device=dev).view(B, 1, 1)
-        f_i = (torch.arange(Ft, device=dev) if Fs == Ft else torch.zeros(Ft, dtype=torch.long, device=dev)).view(1, Ft, 1) + start_frame_idx
-        n_i = torch.arange(N, device=dev).view(1, 1, N)
-        src_index = ((b_i * F + f_i) * N + n_i).reshape(-1).to(torch.int32)[lo:hi].contiguous()
+        # Per-call host work that only depends on the cache / the caller's tensors is kept between calls (keyed by tensor identity + in-place
+        # version): the item -> source-view indices, the uint8 boundary mask and the intrinsics' inverses. The last one matters most: the
+        # inverse is taken on the host (bit-equality with the reference's CPU inverse), i.e. a device -> host copy that waits
+        # for every render still in flight on the stream and leaves the GPU idle until the next launch arrives.
+        memo = self.__dict__.setdefault("_items_memo", {})
+        if len(memo) > 16:
+            memo.clear()
+
+        def memoised(key, refs, make):
+            hit = memo.get(key)
+            if hit is None or any(a is not b for a, b in zip(hit[0], refs)):
+                hit = memo[key] = (refs, make())  # `refs` keeps the keyed tensors alive, so an id() cannot be recycled under the entry
+            return hit[1]
+
+        def make_index():
+            b_i = torch.arange(B, device=dev).view(B, 1, 1)
+            f_i = (torch.arange(Ft, device=dev) if Fs == Ft else torch.zeros(Ft, dtype=torch.long, device=dev)).view(1, Ft, 1) + start_frame_idx
+            n_i = torch.arange(N, device=dev).view(1, 1, N)
+            return ((b_i * F + f_i) * N + n_i).reshape(-1).to(torch.int32)[lo:hi].contiguous()
+
+        src_index = memoised(("idx", B, F, N, Ft, Fs, start_frame_idx, lo, hi), (), make_index)
         w2cs = target_w2cs.to(dev, f32).reshape(B, Ft, 1, 16).expand(B, Ft, N, 16).reshape(-1, 16)[lo:hi].contiguous()
-        Ks = target_intrinsics.to(dev, f32).reshape(B, Ft, 1, 9).expand(B, Ft, N, 9).reshape(-1, 9)[lo:hi].contiguous()
         n_src = B * F * N
         img_src = self.input_image.reshape(n_src, C, H, W).contiguous()  # views when the cache tensors are contiguous (they are)
         pts_src = self.input_points.reshape(n_src, H, W, 3).contiguous()
         msk_src = None if self.input_mask is None else self.input_mask.reshape(n_src, H, W).contiguous()
-        bnd_src = kinv = None
+        ti = target_intrinsics
+
+        def make_K():
+            Ks_ = ti.to(dev, f32).reshape(B, Ft, 1, 9).expand(B, Ft, N, 9).reshape(-1, 9)[lo:hi].contiguous()
+            kinv_ = _host_inverse(Ks_.reshape(-1, 3, 3)).reshape(-1, 9).contiguous() if self.foreground_masking else None
+            return Ks_, kinv_
+
+        Ks, kinv = memoised(("K", id(ti), ti.data_ptr(), _tensor_version(ti), tuple(ti.shape), N, lo, hi, bool(self.foreground_masking)), (ti,), make_K)
+        bnd_src = None
         if self.foreground_masking:
             bm = self.boundary_mask
-            bnd_src = bm.expand(B, F, N, V, 1, H, W).reshape(n_src, H, W).to(torch.uint8).contiguous()
-            kinv = _host_inverse(Ks.reshape(-1, 3, 3)).reshape(-1, 9).contiguous()
+            bnd_src = memoised(("bnd", id(bm), bm.data_ptr(), _tensor_version(bm), B, F, N, V, H, W), (bm,),
+                               lambda: bm.expand(B, F, N, V, 1, H, W).reshape(n_src, H, W).to(torch.uint8).contiguous())
         lib = _lib.load()
         st = _stream()
         for i in range(0, m, step):

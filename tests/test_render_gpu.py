@@ -220,7 +220,10 @@ def test_render_items_call_matches_the_expand_and_loop_form(fg, n_buf):
     """Cache3D.render_cache through g3_render_items_f32 (items name their source view, cached self-cleaning workspace, one preallocated output)
     against the reference-shaped path (sources expanded per item, forward_warp per chunk): masks (=> every splat index / occlusion decision)
     identical, colours / depths equal up to the summation order of the float atomics. Rendered TWICE through the cached workspace: the second
-    render must not see anything the first left behind (the accumulator cleans itself) - with cameras that push corners out of the windows."""
+    render must not see anything the first left behind (the accumulator cleans itself) - with cameras that push corners out of the windows.
+    With foreground masking the items call rasterises a thread-compacted patch list, sweeps camera-plane triangles in a separate pass and applies
+    the occlusion inside the resolve pass; the expand form is the wave-per-patch rasteriser + mesh_apply_kernel that the 704x1280 test above
+    holds against the brute force."""
     from gen3c_amd import renderer
     dev = torch.device("cuda:0")
     h, w, Fn = 96, 160, 7  # odd item count for N = 1: a ragged last pair / chunk
@@ -232,7 +235,15 @@ def test_render_items_call_matches_the_expand_and_loop_form(fg, n_buf):
         w2 = torch.eye(4, device=dev)
         w2[0, 3] = -0.15
         cache.update_cache(t(img[::-1].copy())[None], t(depth * 1.07)[None, None], w2[None], new_intrinsics=t(K)[None], depth_alignment=False)
-    w2cs = torch.stack([torch.from_numpy(_cam(tx=0.05 * i, tz=-0.4 * (i % 3), yaw=0.03 * i)) for i in range(Fn)])[None].to(dev)  # zooming in: corners leave windows
+    cams = [_cam(tx=0.05 * i, tz=-0.4 * (i % 3), yaw=0.03 * i) for i in range(Fn)]  # zooming in: corners leave windows
+    cams[5] = _cam(tx=-0.7, tz=-1.68)  # camera plane through the boundary skirt: triangles behind the camera / straddling z = 0 (the heavy list of the items call)
+    if fg:
+        from oracle import warp_oracle as wo
+        pts_o = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+        _, camp = wo.project_points(pts_o, cams[5][None], K[None])
+        tz_ = wo.mesh_triangles(*wo.downsample_points_mask(camp[0], ~wo.reliable_depth_mask(depth[None, None])[0, 0], 4))[..., 2]
+        assert int((tz_.min(1) <= 1e-4).sum()) > 10, "the case must contain triangles that touch the camera plane"
+    w2cs = torch.stack([torch.from_numpy(c) for c in cams])[None].to(dev)
     Ks = t(K)[None, None].expand(1, Fn, 3, 3).contiguous()
     outs = {}
     for items in (True, False, True):
