@@ -21,6 +21,7 @@
 // -ffp-contract=off): pixel indices and masks are bit-exact w.r.t. the oracle; accumulated floats depend on atomic
 // order (as they do in the reference) and on libm's log1p/exp.
 #include "common.hpp"
+#include <algorithm>
 #include <mutex>
 
 namespace {
@@ -582,8 +583,8 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
                                                                   float* __restrict__ accum, float* __restrict__ frame,
                                                                   float* __restrict__ mask, float* __restrict__ depth, int n, int h, int w,
                                                                   int ntiles, int tiles_x, const unsigned* __restrict__ dirty = nullptr,
-                                                                  unsigned epoch = 0, const unsigned* __restrict__ tmin = nullptr,
-                                                                  const float* __restrict__ Kinv = nullptr) {
+                                                                  unsigned epoch = 0, unsigned* __restrict__ tmin = nullptr,
+                                                                  const float* __restrict__ Kinv = nullptr, const unsigned* __restrict__ occ_stamps = nullptr) {
     __shared__ int lst[256 * 5];  // overlapping source tiles of one scan chunk: tile, ox, oy, ex, ey
     __shared__ int wave_cnt[4];
     const int item = blockIdx.y;
@@ -670,8 +671,9 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
         // mesh occlusion applied here when the rasteriser ran before this pass (g3_render_items_f32): the arithmetic of mesh_apply_kernel on the
         // values this thread is about to write, instead of a separate read-modify-write pass over frame / mask / depth
         float keep = 1.0f;
-        if (tmin) {
+        if (tmin && occ_stamps[(int64_t)item * ntiles + blockIdx.x] == epoch) {  // the rasteriser hit this tile: read its tmin and leave +inf behind
             const unsigned bits = tmin[(int64_t)item * hw + pix];
+            if (bits != 0x7f800000u) tmin[(int64_t)item * hw + pix] = 0x7f800000u;
             const float t = (bits == 0x7f800000u) ? 0.f : __uint_as_float(bits);
             const V3 d = pixel_ray(Kinv + item * 9, gx[k] - 1, gy[k] - 1);
             const float mesh_z = t * d.z;
@@ -767,6 +769,11 @@ __global__ __launch_bounds__(256) void mesh_downsample_kernel(const float* __res
 // per-item counters of the mesh pass live CNT_STRIDE ints apart: counters of different items in ONE cache line serialise in the L2 (32 items x
 // ~300 wave atomics on one line: 95 us for a pass that otherwise takes 5)
 constexpr int CNT_STRIDE = 32;
+// g3_render_items_f32 keeps tmin at +inf between renders: the rasteriser stamps the 32 x 32 output tiles it hits with the render's epoch, and the
+// resolve pass reads tmin only in stamped tiles and puts the +inf back - no per-render fill of tmin and no tmin read where no triangle landed
+// (8 bytes per pixel of traffic for the ~95 % of the tiles without a hit).
+struct OccTiles { unsigned* stamps; int tiles_x; unsigned epoch; };  // stamps of ONE item; nullptr: tmin is filled / read everywhere
+G3_DEVICE unsigned* occ_stamp(const OccTiles& O, int px, int py) { return O.stamps ? O.stamps + (py / TS) * O.tiles_x + px / TS : nullptr; }
 struct TriSetup { V3 e1, e2, s, q; float e2q; };
 G3_DEVICE TriSetup tri_setup(V3 v0, V3 v1, V3 v2) {
     TriSetup t;
@@ -776,7 +783,7 @@ G3_DEVICE TriSetup tri_setup(V3 v0, V3 v1, V3 v2) {
     t.e2q = dot(t.e2, t.q);
     return t;
 }
-G3_DEVICE void ray_tri_min(const TriSetup& T, V3 d, float eps, unsigned* __restrict__ out_px) {
+G3_DEVICE void ray_tri_min(const TriSetup& T, V3 d, float eps, unsigned* __restrict__ out_px, unsigned* __restrict__ stamp = nullptr, unsigned epoch = 0) {
     const V3 hh = cross(d, T.e2);
     const float a = dot(T.e1, hh);
     if (fabsf(a) < eps) return;
@@ -788,29 +795,66 @@ G3_DEVICE void ray_tri_min(const TriSetup& T, V3 d, float eps, unsigned* __restr
     const float t = f * T.e2q;
     // values only ever decrease, so a (possibly stale) read that is already <= t makes the atomic redundant; overlapping skirt triangles
     // cover most pixels several times
-    if (t > eps && __float_as_uint(t) < *(volatile unsigned*)out_px) atomicMin(out_px, __float_as_uint(t));
+    if (t > eps && __float_as_uint(t) < *(volatile unsigned*)out_px) {
+        atomicMin(out_px, __float_as_uint(t));
+        if (stamp) *stamp = epoch;  // this 32 x 32 output tile has a hit in this render: the resolve pass reads (and resets) its tmin, see OccTiles
+    }
 }
-G3_DEVICE void patch_triangle(const float* __restrict__ P, int nw, int patch, int tri, V3& v0, V3& v1, V3& v2) {
-    const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
-    auto vert = [&](int i, int j) -> V3 { const float* p = P + ((int64_t)i * nw + j) * 3; return {p[0], p[1], p[2]}; };
+// Where the vertices of the 4x-downsampled mesh come from: a precomputed [nh][nw][3] array, or computed from the cached world points of the
+// item's source view and the item's world-to-camera matrix with mesh_downsample_kernel's expressions (same operation order, same bits).
+// g3_render_items_f32 computes them in mesh_mark_kernel for the boundary patches only (~2 % of the mesh; downsampling every vertex of every
+// item is 43 us per 32 items of mostly unused work) into the same [nh][nw][3] layout, which the rasteriser then reads.
+struct MeshVerts {
+    const float* P;
+    const float* psrc;
+    const float* W;
+    int h, w, nh, nw;
+};
+G3_DEVICE V3 mesh_vertex(const MeshVerts& M, int i, int j) {
+    if (M.P) {
+        const float* p = M.P + ((int64_t)i * M.nw + j) * 3;
+        return {p[0], p[1], p[2]};
+    }
+    const float sy = (float)M.h / (float)M.nh, sx = (float)M.w / (float)M.nw;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilinear_src(i, sy, M.h, y0, y1, wy0, wy1);
+    bilinear_src(j, sx, M.w, x0, x1, wx0, wx1);
+    float v[3];
+    const float* W = M.W;
+    auto cam_at = [&](int y, int x, int k) -> float {
+        const float* p = M.psrc + ((int64_t)y * M.w + x) * 3;
+        return ((W[k * 4 + 0] * p[0] + W[k * 4 + 1] * p[1]) + W[k * 4 + 2] * p[2]) + W[k * 4 + 3] * 1.0f;
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float top = cam_at(y0, x0, k) * wx0 + cam_at(y0, x1, k) * wx1;
+        const float bot = cam_at(y1, x0, k) * wx0 + cam_at(y1, x1, k) * wx1;
+        v[k] = top * wy0 + bot * wy1;
+    }
+    return {v[0], v[1], v[2]};
+}
+G3_DEVICE void patch_triangle(const MeshVerts& M, int patch, int tri, V3& v0, V3& v1, V3& v2) {
+    const int pi = patch / (M.nw - 1), pj = patch - pi * (M.nw - 1);
     // points_to_mesh: (tl, tr, bl) and (tr, br, bl)
-    v0 = tri == 0 ? vert(pi, pj) : vert(pi, pj + 1);
-    v1 = tri == 0 ? vert(pi, pj + 1) : vert(pi + 1, pj + 1);
-    v2 = vert(pi + 1, pj);
+    v0 = tri == 0 ? mesh_vertex(M, pi, pj) : mesh_vertex(M, pi, pj + 1);
+    v1 = tri == 0 ? mesh_vertex(M, pi, pj + 1) : mesh_vertex(M, pi + 1, pj + 1);
+    v2 = mesh_vertex(M, pi + 1, pj);
 }
 
 // The lanes of a wave sweep the conservative pixel bounding box of one triangle (tri = 0 / 1 of a mesh patch). A triangle that touches the
 // camera plane has no finite projection: its box is the whole image. `heavy` == nullptr: swept here all the same (one wave, h * w / 64 rounds);
-// otherwise it is appended to the item's heavy list and mesh_raster_heavy_kernel spreads its pixels over the chip.
-G3_DEVICE void mesh_raster_tri(int item, int patch, int tri, int lane, const float* __restrict__ pts, const float* __restrict__ Kmat,
-                               const float* __restrict__ Kinv, unsigned* __restrict__ tmin, int h, int w, int nh, int nw, float eps,
-                               int* __restrict__ heavy_cnt, int* __restrict__ heavy, int heavy_cap) {
-    const float* P = pts + (int64_t)item * nh * nw * 3;
+// otherwise its three vertices are appended to the item's heavy list and mesh_raster_heavy_kernel spreads its pixels over the chip (a full
+// list: swept here after all).
+G3_DEVICE void mesh_raster_tri(int item, int patch, int tri, int lane, const MeshVerts& M, const float* __restrict__ Kmat,
+                               const float* __restrict__ Kinv, unsigned* __restrict__ tmin, float eps,
+                               int* __restrict__ heavy_cnt, float* __restrict__ heavy, int heavy_cap, const OccTiles& O) {
+    const int h = M.h, w = M.w;
     const float* K = Kmat + item * 9;
     const float* Ki = Kinv + item * 9;
     unsigned* out = tmin + (int64_t)item * h * w;
     V3 v0, v1, v2;
-    patch_triangle(P, nw, patch, tri, v0, v1, v2);
+    patch_triangle(M, patch, tri, v0, v1, v2);
     int x_lo = 0, x_hi = w - 1, y_lo = 0, y_hi = h - 1;
     if (v0.z > 1e-4f && v1.z > 1e-4f && v2.z > 1e-4f) {
         float minx = 3e38f, maxx = -3e38f, miny = 3e38f, maxy = -3e38f;
@@ -828,18 +872,23 @@ G3_DEVICE void mesh_raster_tri(int item, int patch, int tri, int lane, const flo
         y_hi = min(h - 1, (int)ceilf(fminf(maxy, (float)h + 1.f)) + 1);
         if (x_hi < x_lo || y_hi < y_lo) return;
     } else if (heavy) {
-        if (lane == 0) {
-            const int at = atomicAdd(heavy_cnt + item * CNT_STRIDE, 1);
-            if (at < heavy_cap) heavy[(int64_t)item * heavy_cap + at] = patch * 2 + tri;
+        int at = 0;
+        if (lane == 0) at = atomicAdd(heavy_cnt + item * CNT_STRIDE, 1);
+        at = __shfl(at, 0, 64);
+        if (at < heavy_cap) {
+            if (lane == 0) {
+                float* e = heavy + ((int64_t)item * heavy_cap + at) * 9;
+                e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v1.x; e[4] = v1.y; e[5] = v1.z; e[6] = v2.x; e[7] = v2.y; e[8] = v2.z;
+            }
+            return;
         }
-        return;
     }
     const TriSetup T = tri_setup(v0, v1, v2);
     const int bw = x_hi - x_lo + 1;
     const int npix = bw * (y_hi - y_lo + 1);
     for (int k = lane; k < npix; k += 64) {
         const int py = y_lo + k / bw, px = x_lo + k % bw;
-        ray_tri_min(T, pixel_ray(Ki, px, py), eps, out + (int64_t)py * w + px);
+        ray_tri_min(T, pixel_ray(Ki, px, py), eps, out + (int64_t)py * w + px, occ_stamp(O, px, py), O.epoch);
     }
 }
 
@@ -854,14 +903,16 @@ __global__ __launch_bounds__(256) void mesh_raster_wave_kernel(const float* __re
     const int pi = patch / (nw - 1), pj = patch - pi * (nw - 1);
     const uint8_t* mi = m + (int64_t)item * nh * nw;
     if (!(mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1])) return;
-    for (int tri = 0; tri < 2; ++tri) mesh_raster_tri(item, patch, tri, threadIdx.x & 63, pts, Kmat, Kinv, tmin, h, w, nh, nw, eps, nullptr, nullptr, 0);
+    const MeshVerts M = {pts + (int64_t)item * nh * nw * 3, nullptr, nullptr, h, w, nh, nw};
+    for (int tri = 0; tri < 2; ++tri) mesh_raster_tri(item, patch, tri, threadIdx.x & 63, M, Kmat, Kinv, tmin, eps, nullptr, nullptr, 0, OccTiles{nullptr, 0, 0u});
 }
 
 // g3_render_items_f32: a THREAD per mesh patch tests the boundary mask and the patches that pass are appended to the item's list (one atomic
 // per wave); mesh_raster_list_kernel then gives every listed TRIANGLE to a wave, grid-stride. One wave per patch of the mesh is 1.8 M waves per
 // 32 items of 704 x 1280 of which ~2 % have a boundary patch, and those sit next to each other (the disc outlines), i.e. in few workgroups.
-__global__ __launch_bounds__(256) void mesh_mark_kernel(const uint8_t* __restrict__ m, int* __restrict__ list_cnt, int* __restrict__ list, int list_cap,
-                                                        int n, int nh, int nw) {
+__global__ __launch_bounds__(256) void mesh_mark_kernel(const uint8_t* __restrict__ bmask, const int* __restrict__ src, int* __restrict__ list_cnt,
+                                                        int* __restrict__ list, int list_cap, int n, int h, int w, int nh, int nw,
+                                                        const float* __restrict__ points, const float* __restrict__ w2c, float* __restrict__ pts_ds) {
     const int item = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int npatch = (nh - 1) * (nw - 1);
@@ -869,8 +920,11 @@ __global__ __launch_bounds__(256) void mesh_mark_kernel(const uint8_t* __restric
     bool boundary = false;
     if (mine < npatch) {
         const int pi = mine / (nw - 1), pj = mine - pi * (nw - 1);
-        const uint8_t* mi = m + (int64_t)item * nh * nw;
-        boundary = (mi[pi * nw + pj] | mi[pi * nw + pj + 1] | mi[(pi + 1) * nw + pj] | mi[(pi + 1) * nw + pj + 1]) != 0;
+        const uint8_t* bm = bmask + (int64_t)(src ? src[item] : item) * h * w;
+        const float sy = (float)h / (float)nh, sx = (float)w / (float)nw;
+        // the vertex mask of mesh_downsample_kernel (nearest sample of the boundary mask), read at the patch's four vertices
+        auto vm = [&](int i, int j) -> int { return bm[(int64_t)((int)floorf((float)i * sy)) * w + (int)floorf((float)j * sx)]; };
+        boundary = (vm(pi, pj) | vm(pi, pj + 1) | vm(pi + 1, pj) | vm(pi + 1, pj + 1)) != 0;
     }
     const unsigned long long bal = __ballot(boundary);
     if (bal == 0) return;
@@ -880,32 +934,44 @@ __global__ __launch_bounds__(256) void mesh_mark_kernel(const uint8_t* __restric
     if (boundary) {
         const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
         if (at < list_cap) list[(int64_t)item * list_cap + at] = mine;
+        // the patch's four vertices, computed where they are needed only (~2 % of the mesh; neighbouring patches write the same values twice)
+        const MeshVerts M = {nullptr, points + (int64_t)(src ? src[item] : item) * h * w * 3, w2c + item * 16, h, w, nh, nw};
+        const int pi = mine / (nw - 1), pj = mine - pi * (nw - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = pi + (c >> 1), j = pj + (c & 1);
+            const V3 v = mesh_vertex(M, i, j);
+            float* o = pts_ds + ((int64_t)item * nh * nw + (int64_t)i * nw + j) * 3;
+            o[0] = v.x; o[1] = v.y; o[2] = v.z;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void mesh_raster_list_kernel(const float* __restrict__ pts, const float* __restrict__ Kmat,
+__global__ __launch_bounds__(256) void mesh_raster_list_kernel(const float* __restrict__ pts_ds, const float* __restrict__ Kmat,
                                                                const float* __restrict__ Kinv, unsigned* __restrict__ tmin,
                                                                const int* __restrict__ list_cnt, const int* __restrict__ list, int list_cap, int n,
                                                                int h, int w, int nh, int nw, float eps, int* __restrict__ heavy_cnt,
-                                                               int* __restrict__ heavy, int heavy_cap) {
+                                                               float* __restrict__ heavy, int heavy_cap, unsigned* __restrict__ stamps, int ntiles,
+                                                               int tiles_x, unsigned epoch) {
     const int item = blockIdx.y;
+    const OccTiles O = {stamps + (int64_t)item * ntiles, tiles_x, epoch};
     const int ntri = 2 * min(list_cnt[item * CNT_STRIDE], list_cap);
+    const MeshVerts M = {pts_ds + (int64_t)item * nh * nw * 3, nullptr, nullptr, h, w, nh, nw};
     for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < ntri; e += gridDim.x * 4)
-        mesh_raster_tri(item, list[(int64_t)item * list_cap + (e >> 1)], e & 1, threadIdx.x & 63, pts, Kmat, Kinv, tmin, h, w, nh, nw, eps, heavy_cnt, heavy,
-                        heavy_cap);
+        mesh_raster_tri(item, list[(int64_t)item * list_cap + (e >> 1)], e & 1, threadIdx.x & 63, M, Kmat, Kinv, tmin, eps, heavy_cnt, heavy, heavy_cap, O);
 }
 
 // Triangles on the heavy list against every pixel: a thread owns HEAVY_PX pixels (ray computed once per pixel), the triangles are the inner,
 // wave-uniform loop. Nothing listed (the normal case): the workgroups leave at once.
 constexpr int HEAVY_PX = 8;
-__global__ __launch_bounds__(256) void mesh_raster_heavy_kernel(const float* __restrict__ pts, const float* __restrict__ Kinv,
-                                                                unsigned* __restrict__ tmin, const int* __restrict__ heavy_cnt,
-                                                                const int* __restrict__ heavy, int heavy_cap, int n, int h, int w, int nh,
-                                                                int nw, float eps) {
+__global__ __launch_bounds__(256) void mesh_raster_heavy_kernel(const float* __restrict__ Kinv, unsigned* __restrict__ tmin,
+                                                                const int* __restrict__ heavy_cnt, const float* __restrict__ heavy, int heavy_cap,
+                                                                int n, int h, int w, float eps, unsigned* __restrict__ stamps, int ntiles, int tiles_x,
+                                                                unsigned epoch) {
     const int item = blockIdx.y;
     const int cnt = min(heavy_cnt[item * CNT_STRIDE], heavy_cap);
     if (cnt == 0) return;
-    const float* P = pts + (int64_t)item * nh * nw * 3;
+    const OccTiles O = {stamps + (int64_t)item * ntiles, tiles_x, epoch};
     const float* Ki = Kinv + item * 9;
     unsigned* out = tmin + (int64_t)item * h * w;
     const int hw = h * w;
@@ -915,10 +981,8 @@ __global__ __launch_bounds__(256) void mesh_raster_heavy_kernel(const float* __r
         const int py = pix / w, px = pix - py * w;
         const V3 d = pixel_ray(Ki, px, py);
         for (int i = 0; i < cnt; ++i) {
-            const int e = heavy[(int64_t)item * heavy_cap + i];
-            V3 v0, v1, v2;
-            patch_triangle(P, nw, e >> 1, e & 1, v0, v1, v2);
-            ray_tri_min(tri_setup(v0, v1, v2), d, eps, out + pix);
+            const float* e = heavy + ((int64_t)item * heavy_cap + i) * 9;
+            ray_tri_min(tri_setup({e[0], e[1], e[2]}, {e[3], e[4], e[5]}, {e[6], e[7], e[8]}), d, eps, out + pix, occ_stamp(O, px, py), O.epoch);
         }
     }
 }
@@ -1105,9 +1169,10 @@ extern "C" int g3_reliable_depth_mask_f32(const float* depth, uint8_t* out, int 
  * replicated, and project -> window splat -> gather / resolve -> (mesh occlusion) run back to back on one workspace. */
 namespace {
 struct RenderWs {
-    size_t z, flow, maskz, gmax, accum, windows, origins, dirty, pts_ds, m_ds, tmin, heavy_cnt, heavy, list, total;
+    size_t z, flow, maskz, gmax, accum, windows, origins, dirty, occ, pts_ds, tmin, heavy_cnt, heavy, list, total;
 };
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t render_heavy_cap(size_t nh, size_t nw) { return (nh > 1 && nw > 1) ? std::min((nh - 1) * (nw - 1) * 2, (size_t)16384) : 0; }
 RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
     RenderWs L;
     const size_t hw = (size_t)h * w;
@@ -1117,6 +1182,7 @@ RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
     auto take = [&](size_t bytes) { const size_t at = o; o = align256(o + bytes); return at; };
     L.accum = take((size_t)n * (h + 2) * (w + 2) * ACC_C * sizeof(float));  // first: the part g3_render_workspace_init has to zero
     L.dirty = take((size_t)n * sizeof(unsigned));
+    L.occ = take((size_t)n * ntiles * sizeof(unsigned));  // epoch stamps of the output tiles the occlusion rasteriser hit
     L.z = take(n * hw * sizeof(float));
     L.flow = take(n * hw * 2 * sizeof(float));
     L.maskz = take(n * hw * sizeof(float));
@@ -1124,10 +1190,9 @@ RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
     L.windows = take((size_t)n * ntiles * WIN * WIN * ACC_C * sizeof(float));
     L.origins = take((size_t)n * ntiles * ORG_N * sizeof(int));
     L.pts_ds = take((size_t)n * nh * nw * 3 * sizeof(float));
-    L.m_ds = take((size_t)n * nh * nw);
     L.tmin = take(n * hw * sizeof(unsigned));
     L.heavy_cnt = take((size_t)n * CNT_STRIDE * sizeof(int));  // per item, a 128-byte line of its own: [0] heavy triangles, [1] listed boundary patches
-    L.heavy = take((nh > 1 && nw > 1) ? (size_t)n * (nh - 1) * (nw - 1) * 2 * sizeof(int) : 0);  // every triangle of the mesh could touch the camera plane
+    L.heavy = take((size_t)n * render_heavy_cap(nh, nw) * 9 * sizeof(float));  // vertices of the triangles that touch the camera plane
     L.list = take((nh > 1 && nw > 1) ? (size_t)n * (nh - 1) * (nw - 1) * sizeof(int) : 0);
     L.total = o;
     return L;
@@ -1145,7 +1210,8 @@ extern "C" int g3_render_workspace_init(void* workspace, int n, int h, int w, in
     if (!workspace || ((uintptr_t)workspace & 255)) return g3_set_error(G3_ERR_ARG, "g3_render_workspace_init: workspace must be 256-byte aligned");
     if (n <= 0 || h <= 0 || w <= 0 || group_size <= 0) return g3_set_error(G3_ERR_ARG, "g3_render_workspace_init: bad shape");
     const RenderWs L = render_ws_layout(n, h, w, group_size, 4);
-    hipError_t e = hipMemsetAsync((char*)workspace + L.accum, 0, L.z - L.accum, (hipStream_t)stream);  // accumulators + dirty stamps
+    hipError_t e = hipMemsetAsync((char*)workspace + L.accum, 0, L.z - L.accum, (hipStream_t)stream);  // accumulators + dirty / occlusion stamps
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)((char*)workspace + L.tmin), 0x7f800000, (size_t)n * h * w, (hipStream_t)stream);  // +inf; the renders keep it so
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_workspace_init: memset: %s", hipGetErrorString(e));
     return G3_OK;
 }
@@ -1170,6 +1236,7 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     float* windows = (float*)(ws + L.windows);
     int* origins = (int*)(ws + L.origins);
     unsigned* dirty = (unsigned*)(ws + L.dirty);
+    unsigned* occ = (unsigned*)(ws + L.occ);
     hipStream_t s = (hipStream_t)stream;
     unsigned epoch;
     {
@@ -1186,29 +1253,28 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     unsigned* tmin = nullptr;
     if (boundary_src) {
         const int nh = h / factor, nw = w / factor;
-        float* pts_ds = (float*)(ws + L.pts_ds);
-        uint8_t* m_ds = (uint8_t*)(ws + L.m_ds);
         int* heavy_cnt = (int*)(ws + L.heavy_cnt);
         int* list_cnt = heavy_cnt + 1;
-        int* heavy = (int*)(ws + L.heavy);
+        float* heavy = (float*)(ws + L.heavy);
         int* list = (int*)(ws + L.list);
         tmin = (unsigned*)(ws + L.tmin);
         const int npatch = (nh - 1) * (nw - 1);
-        e = hipMemsetD32Async((hipDeviceptr_t)tmin, 0x7f800000, (size_t)n * h * w, s);  // +inf bit pattern
-        if (e == hipSuccess) e = hipMemsetAsync(heavy_cnt, 0, (size_t)n * CNT_STRIDE * sizeof(int), s);
+        const int heavy_cap = (int)render_heavy_cap(nh, nw);
+        const int mesh_tiles_x = (w + TS - 1) / TS, mesh_ntiles = mesh_tiles_x * ((h + TS - 1) / TS);
+        e = hipMemsetAsync(heavy_cnt, 0, (size_t)n * CNT_STRIDE * sizeof(int), s);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(mesh_downsample_kernel, dim3(grid_x(nh * nw), n), dim3(256), 0, s, (const float*)nullptr, boundary_src, pts_ds, m_ds, n, h, w, nh,
-                           nw, src_index, points_src, w2c);
-        hipLaunchKernelGGL(mesh_mark_kernel, dim3((npatch + 255) / 256, n), dim3(256), 0, s, (const uint8_t*)m_ds, list_cnt, list, npatch, n, nh, nw);
-        hipLaunchKernelGGL(mesh_raster_list_kernel, dim3(256, n), dim3(256), 0, s, (const float*)pts_ds, K, Kinv, tmin, (const int*)list_cnt, (const int*)list,
-                           npatch, n, h, w, nh, nw, 1e-8f, heavy_cnt, heavy, npatch * 2);
-        hipLaunchKernelGGL(mesh_raster_heavy_kernel, dim3((h * w + 256 * HEAVY_PX - 1) / (256 * HEAVY_PX), n), dim3(256), 0, s, (const float*)pts_ds, Kinv, tmin,
-                           (const int*)heavy_cnt, (const int*)heavy, npatch * 2, n, h, w, nh, nw, 1e-8f);
+        float* pts_ds = (float*)(ws + L.pts_ds);
+        hipLaunchKernelGGL(mesh_mark_kernel, dim3((npatch + 255) / 256, n), dim3(256), 0, s, boundary_src, src_index, list_cnt, list, npatch, n, h, w, nh, nw,
+                           points_src, w2c, pts_ds);
+        hipLaunchKernelGGL(mesh_raster_list_kernel, dim3(256, n), dim3(256), 0, s, (const float*)pts_ds, K, Kinv, tmin, (const int*)list_cnt,
+                           (const int*)list, npatch, n, h, w, nh, nw, 1e-8f, heavy_cnt, heavy, heavy_cap, occ, mesh_ntiles, mesh_tiles_x, epoch);
+        hipLaunchKernelGGL(mesh_raster_heavy_kernel, dim3((h * w + 256 * HEAVY_PX - 1) / (256 * HEAVY_PX), n), dim3(256), 0, s, Kinv, tmin,
+                           (const int*)heavy_cnt, (const float*)heavy, heavy_cap, n, h, w, 1e-8f, occ, mesh_ntiles, mesh_tiles_x, epoch);
     }
     const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
                        (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
     hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
-                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, (const unsigned*)tmin, Kinv);
+                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, tmin, Kinv, (const unsigned*)occ);
     return g3_check_launch("g3_render_items_f32");
 }
