@@ -108,13 +108,15 @@ G3_DEVICE SplatGeom splat_geom(float flow_x, float flow_y, int px, int py, int h
     const float tx = flow_x + (float)px, ty = flow_y + (float)py;  // trans_pos = flow12 + grid
     const float ox = tx + 1.0f, oy = ty + 1.0f;
     SplatGeom g;
-    // floor/ceil -> .long() -> clamp; NaN/inf follow the CPU reference (NaN -> INT64_MIN -> clamps to 0)
+    // floor/ceil -> .long() -> clamp; NaN/inf follow the CPU reference (NaN -> INT64_MIN -> clamps to 0). The clamp is taken on the float
+    // (integer-valued, bounds exactly representable: the same result as converting to int64 first, for every input; fmaxf(NaN, 0) = 0) - the
+    // int64 form cost ~60 VALU instructions per pixel in a kernel that is VALU-bound (PMC: profiles/r3_pmc_render.txt)
     const float flx = floorf(ox), clx = ceilf(ox), fly = floorf(oy), cly = ceilf(oy);
-    auto to_ll = [](float f) -> long long { return (f != f) ? (long long)0x8000000000000000ULL : (f >= 9.2e18f ? 0x7fffffffffffffffLL : (f <= -9.2e18f ? (long long)0x8000000000000000ULL : (long long)f)); };
-    g.fx = clampi(to_ll(flx), 0, w + 1);
-    g.cx = clampi(to_ll(clx), 0, w + 1);
-    g.fy = clampi(to_ll(fly), 0, h + 1);
-    g.cy = clampi(to_ll(cly), 0, h + 1);
+    auto clampf = [](float f, int hi) -> int { return (int)fminf(fmaxf(f, 0.f), (float)hi); };
+    g.fx = clampf(flx, w + 1);
+    g.cx = clampf(clx, w + 1);
+    g.fy = clampf(fly, h + 1);
+    g.cy = clampf(cly, h + 1);
     const float oxc = fminf(fmaxf(ox, 0.f), (float)(w + 1));
     const float oyc = fminf(fmaxf(oy, 0.f), (float)(h + 1));
     const float wy_f = 1.0f - (oyc - (float)g.fy);
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     float Ew[4][2], colk[4][4];  // east corners stay products of the pixel's (r g b z) and a weight until somebody needs the values
     int tw[4][2], te[4][2];
     int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+    const float inv_lmax = 1.0f / (lmax + 1e-7f);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         tw[k][0] = tw[k][1] = te[k][0] = te[k][1] = -1;
@@ -359,16 +362,19 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
             const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
             const float z = zin[k];
             const SplatGeom gk = splat_geom(flx[k], fly[k], px, py, h, w);
-            const float logd = log1pf(fmaxf(z, 0.f));
-            const float expo = logd / (lmax + 1e-7f) * 50.0f;
-            const float dw = expf(fminf(expo, 80.0f)) + 1e-7f;
+            // depth weight exp(log1p(z) / max * 50): hardware log2 / exp2 and reciprocals instead of libm and IEEE divisions (this kernel is
+            // VALU-bound). ~1e-5 relative on a weight that appears in numerator and denominator of the resolve; indices and masks do not depend on it
+            const float logd = __logf(1.0f + fmaxf(z, 0.f));
+            const float expo = logd * inv_lmax * 50.0f;
+            const float dw = __expf(fminf(expo, 80.0f)) + 1e-7f;
             const float m = mk[k];
             colk[k][0] = rgb[k][0]; colk[k][1] = rgb[k][1]; colk[k][2] = rgb[k][2]; colk[k][3] = z;
             mnx = min(mnx, gk.fx);
             mny = min(mny, gk.fy);
             mxx = max(mxx, gk.cx);
             mxy = max(mxy, gk.cy);
-            const float wts[4] = {gk.nw * m * 1.0f / dw, gk.sw * m * 1.0f / dw, gk.ne * m * 1.0f / dw, gk.se * m * 1.0f / dw};
+            const float m_dw = m * __builtin_amdgcn_rcpf(dw);
+            const float wts[4] = {gk.nw * m_dw, gk.sw * m_dw, gk.ne * m_dw, gk.se * m_dw};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Wv[k][0][e] = colk[k][e] * wts[0]; Wv[k][1][e] = colk[k][e] * wts[1]; }
             Wv[k][0][4] = wts[0]; Wv[k][1][4] = wts[1]; Ew[k][0] = wts[2]; Ew[k][1] = wts[3];

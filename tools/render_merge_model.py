@@ -16,13 +16,14 @@ def geom(tx):
     ox=((u-xs).astype(f)+xs+1).astype(f); oy=((v-ys).astype(f)+ys+1).astype(f)
     cl=lambda a,hi: np.clip(a,0,hi).astype(np.int64)
     return cl(np.floor(ox),w+1),cl(np.ceil(ox),w+1),cl(np.floor(oy),h+1),cl(np.ceil(oy),h+1)
-def sim_tile(FX,CX,FY,CY,ty0,tx0, general=True):
+def sim_tile(FX,CX,FY,CY,ty0,tx0, general=True, census=False):
     # returns (#store corners, #atomic corners) ; values modelled as 1.0 weights to check conservation
     tot_atomic=0; tot_store=0
     contrib={}  # texel -> total (for conservation)
     final={}
     owner={}
     pend=[]  # (tex, val, kind)
+    log=[]
     for wv in range(4):
         # wave: lanes 0..63 ; thread t = wv*64+lane ; rows ty0 + 4*(t>>5) + k ; col tx0 + (t&31)
         TW=np.full((64,4,2),-1,np.int64); TE=np.full((64,4,2),-1,np.int64)
@@ -106,21 +107,73 @@ def sim_tile(FX,CX,FY,CY,ty0,tx0, general=True):
         for lane in range(64):
             for k in range(4):
                 for c in range(2):
-                    if TW[lane,k,c]>=0: pend.append((TW[lane,k,c],W[lane,k,c],'w' if (general or c==0) else 'a'))
-                    if TE[lane,k,c]>=0: pend.append((TE[lane,k,c],E[lane,k,c],'a'))
-    # owner: last writer among 'w' candidates wins
-    for i,(T,v,kind) in enumerate(pend):
-        if kind=='w': owner[T]=i
+                    if TW[lane,k,c]>=0: pend.append((TW[lane,k,c],W[lane,k,c],'w' if (general or c==0) else 'a')); log.append((int(TW[lane,k,c]),wv,lane,k,c,'w'))
+                    if TE[lane,k,c]>=0: pend.append((TE[lane,k,c],E[lane,k,c],'a')); log.append((int(TE[lane,k,c]),wv,lane,k,c,'e'))
+    if census: return log
+    # ownership rounds. mode 0: west corners claim, winners store, rest atomics (round 3 kernel before the east corners joined);
+    # mode 1: every corner claims in round 1; mode 2: mode 1 + a second claim round whose winners add with plain read-modify-write
     for i,(T,v,kind) in enumerate(pend):
         final[T]=final.get(T,0)+v
-        if kind=='w' and owner[T]==i: tot_store+=1
-        else: tot_atomic+=1
+    alive=list(range(len(pend)))
+    cand=[i for i in alive if (pend[i][2]=='w' or MODE>=1)]
+    for i in cand: owner[pend[i][0]]=i
+    win=set(i for i in cand if owner[pend[i][0]]==i)
+    tot_store+=len(win)
+    rest=[i for i in alive if i not in win]
+    if MODE>=2:
+        owner2={}
+        for i in rest: owner2[pend[i][0]]=i
+        win2=set(i for i in rest if owner2[pend[i][0]]==i)
+        tot_store+=0
+        globals()['RMW']=globals().get('RMW',0)+len(win2)
+        rest=[i for i in rest if i not in win2]
+    tot_atomic+=len(rest)
     assert final.keys()==contrib.keys() and all(abs(final[t]-contrib[t])<1e-9 for t in contrib), "conservation"
     return tot_store,tot_atomic
 for tx in (0.1,0.3):
-    G=geom(tx)
-    for general in (False,True):
+  G=geom(tx)
+  for MODE in (0,1,2):
+    RMW=0
+    for general in (True,):
         S=A=0;n=0
         for (ty0,tx0) in ((0,0),(320,640),(256,352),(480,896),(672,1248),(160,96)):
             s,a=sim_tile(*G,ty0,tx0,general); S+=s;A+=a;n+=1024
-        print('tx',tx,'general' if general else 'current','stores/pixel %.3f'%(S/n),'atomic corners/pixel %.3f'%(A/n))
+        print('tx',tx,'mode',MODE,'stores/pixel %.3f'%(S/n),'rmw/pixel %.3f'%(RMW/n),'atomic corners/pixel %.3f'%(A/n))
+
+
+def conflict_census(tx=0.3, tile=(320, 640)):
+    """Who still shares a texel after the register merges (why a corner is left for the atomics)."""
+    import collections
+    G = geom(tx)
+    global MODE
+    MODE = 0
+    pend_log = []
+    orig = sim_tile.__globals__.get('_census')
+    FX, CX, FY, CY = G
+    ty0, tx0 = tile
+    # re-run the merge of sim_tile but keep (wave, lane, k, c, kind) per pending corner
+    out = collections.Counter()
+    per_tex = collections.defaultdict(list)
+    for rec in sim_tile(FX, CX, FY, CY, ty0, tx0, True, census=True):
+        per_tex[rec[0]].append(rec[1:])
+    for T, lst in per_tex.items():
+        if len(lst) < 2:
+            continue
+        lst.sort()
+        for a, b in zip(lst, lst[1:]):
+            (w1, l1, k1, c1, kd1), (w2, l2, k2, c2, kd2) = a, b
+            if w1 != w2:
+                out['different waves'] += 1
+            elif l1 == l2:
+                out[f'same thread rows {k1},{k2}'] += 1
+            elif abs(l1 - l2) == 32:
+                out[f'lane +-32 rows {k1},{k2}'] += 1
+            elif abs(l1 - l2) == 1:
+                out[f'neighbour lanes kinds {kd1}{kd2} rows {k1},{k2}'] += 1
+            else:
+                out[f'lanes {abs(l1-l2)} apart'] += 1
+    return out
+
+
+if __name__ == "__main__":
+    print(conflict_census())
