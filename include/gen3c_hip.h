@@ -210,7 +210,10 @@ int g3_warp_splat_resolve_f32(const float* image, const float* z, const float* f
  * group_size pairing). Outputs frame [n][3][h][w], mask [n][h][w], depth [n][h][w] or NULL, flow_out [n][2][h][w] or NULL.
  * workspace: g3_render_workspace_bytes(n, h, w, group_size) bytes, 256-byte aligned, prepared ONCE by g3_render_workspace_init for exactly this
  * (n, h, w, group_size) and then reused call after call: the dense out-of-window accumulator inside it is kept all-zero by the kernels
- * themselves (items whose accumulator a launch touched are stamped, and only those are read back and cleared), so no per-call clearing pass. */
+ * themselves (items whose accumulator a launch touched are stamped, and only those are read back and cleared), so no per-call clearing pass;
+ * likewise the nearest-hit buffer of the occlusion pass is left at +inf by the resolve pass (per-tile stamps). With foreground masking the
+ * occlusion is applied inside the resolve pass (the arithmetic of g3_mesh_occlusion_f32's apply step on the values being written). Limits:
+ * h < 32766, w < 65534 (packed texel ids); calls that share a workspace must be ordered (same stream). */
 size_t g3_render_workspace_bytes(int n, int h, int w, int group_size);
 int g3_render_workspace_init(void* workspace, int n, int h, int w, int group_size, void* stream);
 int g3_render_items_f32(const float* points_src, const float* image_src, const float* mask_src, const uint8_t* boundary_src,
