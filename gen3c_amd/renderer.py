@@ -79,9 +79,10 @@ _RENDER_WS: dict = {}
 
 
 def _render_workspace(lib, n: int, h: int, w: int, group_size: int, dev, stream) -> torch.Tensor:
-    """Workspace of g3_render_items_f32, cached per (n, h, w, group_size, device) and prepared once (g3_render_workspace_init): the kernels
-    keep its accumulator part zero themselves, so a render never clears anything. Launches are ordered on the stream."""
-    key = (n, h, w, group_size, str(dev))
+    """Workspace of g3_render_items_f32, cached per (n, h, w, group_size, device, stream) and prepared once (g3_render_workspace_init): the
+    kernels keep its accumulator part zero themselves, so a render never clears anything. Launches that share a workspace are ordered on its
+    stream (renders issued from two streams get two workspaces)."""
+    key = (n, h, w, group_size, str(dev), int(stream or 0))
     t = _RENDER_WS.get(key)
     if t is None:
         nbytes = int(lib.g3_render_workspace_bytes(n, h, w, group_size))
@@ -89,7 +90,7 @@ def _render_workspace(lib, n: int, h: int, w: int, group_size: int, dev, stream)
         off = (-t.data_ptr()) % 256
         t = t[off:off + nbytes]
         _lib.check(lib.g3_render_workspace_init(t.data_ptr(), n, h, w, group_size, stream), "g3_render_workspace_init")
-        while len(_RENDER_WS) >= 4:  # chunk size + a ragged tail per resolution: bounded
+        while len(_RENDER_WS) >= 4:  # chunk size + a ragged tail per resolution (and stream): bounded
             _RENDER_WS.pop(next(iter(_RENDER_WS)))
         _RENDER_WS[key] = t
     return t

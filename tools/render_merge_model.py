@@ -130,15 +130,25 @@ def sim_tile(FX,CX,FY,CY,ty0,tx0, general=True, census=False):
     tot_atomic+=len(rest)
     assert final.keys()==contrib.keys() and all(abs(final[t]-contrib[t])<1e-9 for t in contrib), "conservation"
     return tot_store,tot_atomic
-for tx in (0.1,0.3):
-  G=geom(tx)
-  for MODE in (0,1,2):
-    RMW=0
-    for general in (True,):
-        S=A=0;n=0
-        for (ty0,tx0) in ((0,0),(320,640),(256,352),(480,896),(672,1248),(160,96)):
-            s,a=sim_tile(*G,ty0,tx0,general); S+=s;A+=a;n+=1024
-        print('tx',tx,'mode',MODE,'stores/pixel %.3f'%(S/n),'rmw/pixel %.3f'%(RMW/n),'atomic corners/pixel %.3f'%(A/n))
+TILES = ((0, 0), (320, 640), (256, 352), (480, 896), (672, 1248), (160, 96))
+
+
+def report():
+    """positional = the round-2 merge rule (same rows, same corner); texel = the texel-id rule of warp_splat_windows_kernel, with the ownership
+    variants: 0 west corners claim a texel, the rest is added atomically (the kernel), 1 east corners claim too, 2 a second claim round whose
+    winners add with a plain read-modify-write (neither built: the kernel is VALU-bound, not LDS-bound, after the merge)."""
+    global MODE, RMW
+    for tx in (0.1, 0.3):
+        G = geom(tx)
+        for general, modes in ((False, (0,)), (True, (0, 1, 2))):
+            for MODE in modes:
+                RMW = 0
+                S = A = n = 0
+                for (ty0, tx0) in TILES:
+                    s_, a_ = sim_tile(*G, ty0, tx0, general)
+                    S += s_; A += a_; n += 1024
+                print(f"camera tx {tx}: {'texel-id' if general else 'positional'} merge, ownership mode {MODE}: stores/pixel {S / n:.3f}, "
+                      f"rmw/pixel {RMW / n:.3f}, atomic corners/pixel {A / n:.3f}")
 
 
 def conflict_census(tx=0.3, tile=(320, 640)):
@@ -176,4 +186,5 @@ def conflict_census(tx=0.3, tile=(320, 640)):
 
 
 if __name__ == "__main__":
-    print(conflict_census())
+    report()
+    print("texel conflicts left in a background tile:", dict(conflict_census()))
