@@ -262,3 +262,35 @@ def test_render_items_call_matches_the_expand_and_loop_form(fg, n_buf):
     assert 0.2 < float(m1.mean()) < 1.0
     for a, b in ((p1, p2), (p3, p2), (d1, d2), (d3, d2)):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"max diff {float((a - b).abs().max()):.3e}"
+
+
+def test_render_items_host_memo_follows_in_place_edits_of_the_callers_tensors():
+    """Cache3D._render_items keeps the intrinsics' host inverse, the uint8 boundary mask and the item -> source indices between calls, keyed by
+    tensor identity + in-place version. An in-place edit of the intrinsics tensor between two renders must be seen (a stale inverse would leave
+    the occlusion rays of the first call), and so must an edit of the boundary mask."""
+    from gen3c_amd import renderer
+    dev = torch.device("cuda:0")
+    h, w, Fn = 96, 160, 4
+    depth, img, K = _scene(h, w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mk = lambda: renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                         input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=True, input_format=["B", "C", "H", "W"])
+    cache = mk()
+    w2cs = torch.stack([torch.from_numpy(_cam(tx=0.1 * (i + 1))) for i in range(Fn)])[None].to(dev)
+    Ks = t(K)[None, None].expand(1, Fn, 3, 3).contiguous()
+    p0, m0 = cache.render_cache(w2cs, Ks)
+    p0b, m0b = cache.render_cache(w2cs, Ks)  # memo hit
+    assert torch.equal(m0, m0b) and torch.allclose(p0, p0b, rtol=1e-4, atol=1e-5)
+    Ks[:, :, 0, 0] *= 1.25  # in place: same tensor object, same storage
+    Ks[:, :, 1, 1] *= 1.25
+    p1, m1 = cache.render_cache(w2cs, Ks)
+    p_ref, m_ref = mk().render_cache(w2cs, Ks.clone())
+    torch.cuda.synchronize()
+    assert not torch.equal(m1, m0), "the edit must change the render"
+    assert torch.equal(m1, m_ref) and torch.allclose(p1, p_ref, rtol=1e-4, atol=1e-5), "stale intrinsics / inverse reused after an in-place edit"
+    cache.boundary_mask.zero_()  # no boundary patches any more: nothing is occluded
+    _, m2 = cache.render_cache(w2cs, Ks)
+    fresh = mk()
+    fresh.boundary_mask.zero_()
+    _, m2_ref = fresh.render_cache(w2cs, Ks.clone())
+    assert torch.equal(m2, m2_ref) and not torch.equal(m2, m1), "stale boundary mask reused after an in-place edit"
