@@ -3,7 +3,7 @@
 Mirrors (same names, argument meaning, CP behaviour):
   * diffusers 0.32.2 `EDMEulerScheduler(sigma_max=80, sigma_min=0.0002, sigma_data=0.5)` as used at
     cosmos_predict1/diffusion/model/model_t2w.py:65 (restated - diffusers is a third-party dependency that is not
-    vendored in the reference; "parity unpinned", see oracle/sampler_oracle.py);
+    vendored in the reference; anchored on diffusers' own full-loop known answer, tests/test_scheduler_kat_cpu.py);
   * `DiffusionV2WModel.generate_samples_from_batch / _augment_noise_with_latent / _reverse_precondition_*`
     (model_v2w.py:84-155, 201-259) and `add_condition_video_indicator_and_video_input_mask` (model_v2w.py:32-82);
   * `VideoExtendCondition` (conditioner.py:107-134).

@@ -1,7 +1,11 @@
 """CPU oracle for the EDM-Euler sampling step of GEN3C (TEST INFRASTRUCTURE - never imported by gen3c_amd/).
 
-PARITY UNPINNED: the scheduler arithmetic lives in diffusers==0.32.2 (requirements.txt:5 of the reference), which is
-neither vendored under /root/reference nor installed here; it is restated from its published algorithm
+PARITY: the scheduler arithmetic lives in diffusers==0.32.2 (requirements.txt:5 of the reference), which is neither
+vendored under /root/reference nor installed here, so it cannot be pinned by running it ("parity unpinned" in that
+sense). It is anchored on diffusers' OWN known answer instead - denoise_step run as the loop of diffusers'
+tests/schedulers/test_scheduler_edm_euler.py::test_full_loop_no_noise reproduces that test's constant (sum|x| = 34.1855
++- 1e-3; tests/test_scheduler_kat_cpu.py) - and on float64 evaluations of Karras et al. 2022 eq. 5 / Table 1. Restated
+from the published algorithm
 (EDMEulerScheduler: Karras rho=7 sigmas, timesteps = 0.25*ln(sigma), init_noise_sigma = sqrt(sigma_max^2+1),
 scale_model_input = x / sqrt(sigma^2 + sigma_data^2), step: x0 = c_skip*x + c_out*eps_out, Euler update with dt =
 sigma_next - sigma). The loop body follows the reference's own call sites: model_v2w.py:130-149 and 201-259.

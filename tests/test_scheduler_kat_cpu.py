@@ -37,3 +37,54 @@ def test_karras_schedule_and_preconditioning_known_answers():
     x = torch.tensor([3.0])
     nxt = x + (x - 0.0) / sch.sigmas[10] * (sch.sigmas[11] - sch.sigmas[10])
     assert math.isclose(float(nxt), 3.0 * float(sch.sigmas[11]) / float(sch.sigmas[10]), rel_tol=1e-6)
+
+
+# diffusers' OWN known answer for this scheduler: tests/schedulers/test_scheduler_edm_euler.py::EDMEulerSchedulerTest::test_full_loop_no_noise
+# (public repository, v0.32.x) runs EDMEulerScheduler(num_train_timesteps=256, sigma_min=0.002, sigma_max=80.0) for 10 steps on
+# SchedulerCommonTest's deterministic sample (arange(4*3*8*8) / 768, reshaped (3, 8, 8, 4), permuted to (4, 3, 8, 8), times
+# init_noise_sigma) with the dummy model `sample * t / (t + 1)` (t = the scheduler's timestep 0.25 ln sigma), through scale_model_input
+# and step, and asserts |sum(|x|) - 34.1855| < 1e-3 and |mean(|x|) - 0.044| < 1e-3. diffusers cannot be imported here (not vendored, no
+# network), so the two constants are quoted from that file; they are self-consistent (34.1855 / 768 = 0.0445) and an independent
+# implementation reproducing the sum to 3e-4 is the check that both the quotation and the restatement are right.
+DIFFUSERS_FULL_LOOP_SUM, DIFFUSERS_FULL_LOOP_MEAN, DIFFUSERS_TOL = 34.1855, 0.044, 1e-3
+
+
+def _diffusers_dummy_sample():
+    n = 4 * 3 * 8 * 8
+    return (torch.arange(n).reshape(3, 8, 8, 4) / n).permute(3, 0, 1, 2)
+
+
+def test_product_scheduler_reproduces_diffusers_full_loop_known_answer():
+    """sigmas / timesteps / init_noise_sigma of gen3c_amd.sampler.EDMEulerScheduler under diffusers' test configuration, driven through
+    the published scale_model_input / step arithmetic (c_in, c_skip, c_out, Euler with dt = sigma_next - sigma) in fp32."""
+    from gen3c_amd.sampler import EDMEulerScheduler
+    sch = EDMEulerScheduler(sigma_max=80.0, sigma_min=0.002, sigma_data=0.5)
+    sch.set_timesteps(10)
+    sd = 0.5
+    x = _diffusers_dummy_sample() * sch.init_noise_sigma
+    for i, t in enumerate(sch.timesteps):
+        s = sch.sigmas[i]
+        scaled = x * (1 / (s ** 2 + sd ** 2) ** 0.5)                                  # scale_model_input
+        out = scaled * t / (t + 1)                                                    # dummy model
+        x0 = sd ** 2 / (s ** 2 + sd ** 2) * x + s * sd / (s ** 2 + sd ** 2) ** 0.5 * out  # precondition_outputs (epsilon prediction)
+        x = x + (x - x0) / s * (sch.sigmas[i + 1] - s)                                # step
+    assert abs(float(x.abs().sum()) - DIFFUSERS_FULL_LOOP_SUM) < DIFFUSERS_TOL, float(x.abs().sum())
+    assert abs(float(x.abs().mean()) - DIFFUSERS_FULL_LOOP_MEAN) < DIFFUSERS_TOL
+
+
+def test_oracle_denoise_step_reproduces_diffusers_full_loop_known_answer(monkeypatch):
+    """The same loop through oracle.sampler_oracle.denoise_step (the checker of the HIP sampling step): no condition region (indicator 0),
+    guidance 0, the dummy model fed the exact fp32 timestep (the oracle hands the network the bf16-cast timestep the reference's loop
+    produces, model_v2w.py:141 - a property of GEN3C's loop, not of the scheduler)."""
+    from oracle import sampler_oracle as so
+    monkeypatch.setattr(so, "SIGMA_MIN", 0.002)
+    n_steps = 10
+    sig = so.karras_sigmas(n_steps)
+    x = _diffusers_dummy_sample()[None].reshape(1, 4, 3, 8, 8) * (so.SIGMA_MAX ** 2 + 1) ** 0.5
+    zeros = torch.zeros_like(x)
+    for i in range(n_steps):
+        t32 = 0.25 * torch.log(sig[i])
+        x = so.denoise_step(lambda inp, t, pose: inp * t32 / (t32 + 1), x, i, gt_latent=zeros, indicator=torch.zeros(1, 1, 3, 1, 1), pose=zeros,
+                            num_steps=n_steps, guidance=0.0, augment_sigma=0.001, seed=0)
+    assert abs(float(x.abs().sum()) - DIFFUSERS_FULL_LOOP_SUM) < DIFFUSERS_TOL, float(x.abs().sum())
+    assert abs(float(x.abs().mean()) - DIFFUSERS_FULL_LOOP_MEAN) < DIFFUSERS_TOL
