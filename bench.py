@@ -139,7 +139,14 @@ def stage_rooflines(dev):
     tm.stop()
     per_item = tm.elapsed_ms() / 3 / F
     gbs = 43.2e6 / (per_item * 1e-3) / 1e9
+    traffic = traffic_source = None  # memory-side bytes per item: QUOTED from the committed rocprofv3 PMC passes of this configuration
+    try:
+        tj = json.loads((ROOT / "profiles" / "r3_render_traffic.json").read_text())
+        traffic, traffic_source = tj["traffic_bytes_per_item"], "profiles/r3_render_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
+    except Exception:
+        pass
     out["roofline_render"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(gbs, 1), frac=round(gbs / 8000.0, 4), ms_per_item=round(per_item, 4),
+                                  traffic=traffic, traffic_source=traffic_source,
                                   workload="cache render (project + splat + mesh occlusion + resolve), 704x1280 items, foreground masking, 43.2 MB algorithmic per item")
     return out
 
