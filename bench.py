@@ -130,14 +130,16 @@ def stage_rooflines(dev):
     Ks = K[None, None].expand(1, F, 3, 3).contiguous()
     cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=img[None], input_depth=depth[None, None], input_w2c=torch.eye(4, device=dev)[None],
                                     input_intrinsics=K[None], filter_points_threshold=0.05, foreground_masking=True, input_format=["B", "C", "H", "W"])
-    cache.render_cache(w2cs, Ks)
+    for _ in range(2):  # workspace / host memo set up, clocks back up after the host-side cache construction
+        cache.render_cache(w2cs, Ks)
     torch.cuda.synchronize()
     tm = ops.HipTimer()
+    reps = 10  # ~13 ms of GPU work (3 repetitions = 4 ms sat inside the clock ramp after an idle gap)
     tm.start()
-    for _ in range(3):
+    for _ in range(reps):
         cache.render_cache(w2cs, Ks)
     tm.stop()
-    per_item = tm.elapsed_ms() / 3 / F
+    per_item = tm.elapsed_ms() / reps / F
     gbs = 43.2e6 / (per_item * 1e-3) / 1e9
     traffic = traffic_source = None  # memory-side bytes per item: QUOTED from the committed rocprofv3 PMC passes of this configuration
     try:
