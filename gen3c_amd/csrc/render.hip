@@ -19,7 +19,10 @@
 //
 // Arithmetic: fp32 with the explicit operation order of oracle/warp_oracle.py (the library is built with
 // -ffp-contract=off): pixel indices and masks are bit-exact w.r.t. the oracle; accumulated floats depend on atomic
-// order (as they do in the reference) and on libm's log1p/exp.
+// order (as they do in the reference) and on the log / exp of the depth weight (hardware log2 / exp2 in the window splat, ~1e-5 relative).
+// One deliberate difference on garbage input: a NaN camera-space z makes the reference's `log_depth1.max()` NaN, which poisons the weights
+// of EVERY pixel of the call (nan_to_num then marks all of them valid with NaN colours); here fmaxf ignores the NaN, the pixel itself is
+// masked by `z > 0` and the rest renders normally. GEN3C never produces NaN points (unproject zeroes points whose depth is <= 0).
 #include "common.hpp"
 #include <algorithm>
 #include <mutex>

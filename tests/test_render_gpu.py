@@ -294,3 +294,60 @@ def test_render_items_host_memo_follows_in_place_edits_of_the_callers_tensors():
     fresh.boundary_mask.zero_()
     _, m2_ref = fresh.render_cache(w2cs, Ks.clone())
     assert torch.equal(m2, m2_ref) and not torch.equal(m2, m1), "stale boundary mask reused after an in-place edit"
+
+
+@pytest.mark.parametrize("case", ["all_masked", "behind_camera", "single_pixel", "camera_plane_points", "ragged_zoom_out"])
+def test_render_items_edge_cases_vs_oracle(case):
+    """Edge inputs through Cache3D.render_cache (g3_render_items_f32) at a frame size that is not a multiple of the 32 x 32 tiles (40 x 72), against
+    the oracle: nothing valid (empty input mask / every point behind the target camera), ONE valid pixel, points ON the camera plane (z = 0: masked,
+    their u = x / 1e-7 lands ~1e7 pixels outside and is clamped) and just in front of it (z = 1e-9: valid, clamped into the cropped border),
+    and a zoom-out that folds many source pixels into few texels (many-to-one
+    overlaps: the register merge must fall back to atomics without losing a contribution). Masks bit-exact, colours within the renderer's bound."""
+    from gen3c_amd import renderer
+    from oracle import warp_oracle as wo
+    dev = torch.device("cuda:0")
+    h, w = 40, 72
+    depth, img, K = _scene(h, w)
+    K = K.copy()
+    K[0, 0] = K[1, 1] = 60.0
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=_t(img, dev)[None], input_depth=_t(depth, dev)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                    input_intrinsics=_t(K, dev)[None], filter_points_threshold=0.05, foreground_masking=False, input_format=["B", "C", "H", "W"])
+    pts = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    msk = wo.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    cams = [_cam(tx=0.2), _cam(tx=-0.3, tz=-0.5)]
+    if case == "all_masked":
+        msk = np.zeros_like(msk)
+    elif case == "behind_camera":
+        cams = [_cam(tz=-30.0), _cam(tz=-50.0)]  # every point ends up at z < 0
+    elif case == "single_pixel":
+        msk = np.zeros_like(msk)
+        msk[0, 0, 17, 33] = 1.0
+    elif case == "camera_plane_points":
+        pts = pts.copy()
+        pts[0, 5:9, 10:30, 2] = 0.0
+        pts[0, 20, 40:44, 2] = 1e-9
+        cams = [_cam(tx=0.2), _cam(tx=-0.3)]  # no z translation: the edited points stay at z = 0 / 1e-9 in both target cameras
+    elif case == "ragged_zoom_out":
+        cams = [_cam(tz=6.0), _cam(tx=0.4, tz=9.0)]  # the scene shrinks to a fraction of the frame
+    cache.input_points = _t(pts, dev).reshape(cache.input_points.shape).to(cache.input_points.dtype)
+    cache.input_mask = _t(msk, dev).reshape(cache.input_mask.shape).to(cache.input_mask.dtype)
+    w2cs = np.stack(cams)
+    pix, m = cache.render_cache(_t(w2cs, dev)[None], _t(K, dev)[None, None].expand(1, 2, 3, 3))
+    pix2, m2 = cache.render_cache(_t(w2cs, dev)[None], _t(K, dev)[None, None].expand(1, 2, 3, 3))  # cached workspace: must be clean again
+    torch.cuda.synchronize()
+    with np.errstate(all="ignore"):
+        fr_o, m_o, _, _, _ = wo.forward_warp(np.broadcast_to(img[None], (2, 3, h, w)), np.broadcast_to(msk, (2, 1, h, w)), np.broadcast_to(pts, (2, h, w, 3)), w2cs,
+                                             np.broadcast_to(K[None], (2, 3, 3)))
+    got_m, got = m[0, :, 0].cpu().numpy(), pix[0, :, 0].cpu().numpy()
+    assert np.array_equal(got_m, m_o), f"{case}: mask differs on {(got_m != m_o).sum()} px"
+    assert torch.equal(m, m2) and torch.allclose(pix, pix2, rtol=1e-4, atol=1e-5), f"{case}: second render through the cached workspace differs"
+    if case in ("all_masked", "behind_camera"):
+        assert got_m.sum() == 0 and np.all(got == -1.0)
+    if case == "single_pixel":
+        assert 1 <= got_m.sum() <= 8
+    if case == "ragged_zoom_out":
+        assert 0 < got_m.mean() < 0.5
+    err = np.abs(got - fr_o)
+    bad = err > (1e-4 + 1e-3 * np.abs(fr_o))
+    print(f"[render edge {case}] valid px {int(got_m.sum())}; colour outliers {int(bad.sum())}/{bad.size}, max abs err {np.nanmax(err):.3e}")
+    assert bad.mean() < 1e-3 and np.nanmax(err) < 5e-2
