@@ -1217,6 +1217,17 @@ RenderWs render_ws_layout(int n, int h, int w, int group_size, int factor) {
 }
 unsigned g_render_epoch = 0;  // stamps the items whose dense accumulator a launch touched; any value that differs from earlier launches' works
 std::mutex g_render_epoch_mu;
+// Side stream of the occlusion pass (one per device, created on first use): marking / rasterising the boundary mesh reads the cached world points
+// and cameras only, nothing the projection or the splat produce, and it is a latency-bound pass that leaves most of the chip idle - so it runs
+// next to project + splat (VALU-bound) and joins before the resolve pass.
+hipStream_t g_render_side[16] = {};
+hipStream_t render_side_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_render_epoch_mu);
+    if (!g_render_side[dev] && hipStreamCreateWithFlags(&g_render_side[dev], hipStreamNonBlocking) != hipSuccess) g_render_side[dev] = nullptr;
+    return g_render_side[dev];
+}
 }  // namespace
 
 extern "C" size_t g3_render_workspace_bytes(int n, int h, int w, int group_size) {
@@ -1265,11 +1276,18 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     if (h + 2 > 32767 || w + 2 > 65535) return g3_set_error(G3_ERR_ARG, "g3_render_items_f32: image too large for the packed texel ids (h < 32766, w < 65534)");
     hipError_t e = hipMemsetAsync(gmax, 0, ((size_t)(n + group_size - 1) / group_size) * sizeof(unsigned), s);
     if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
-                       gmax, n, h, w, group_size, src_index);
     // mesh occlusion: downsampled mesh of the boundary patches -> per-pixel nearest hit (tmin); the resolve pass below applies it
     unsigned* tmin = nullptr;
+    hipEvent_t ev_join = nullptr;
     if (boundary_src) {
+        // fork: everything already queued on `s` (the previous render's resolve pass puts tmin / the stamps back) precedes the side stream's work
+        hipStream_t ms = s;
+        hipStream_t side = g3_opt_render_overlap ? render_side_stream() : nullptr;
+        hipEvent_t ev_fork = nullptr;
+        if (side && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess &&
+            hipEventRecord(ev_fork, s) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess)
+            ms = side;
+        if (ev_fork) (void)hipEventDestroy(ev_fork);  // released once the wait it feeds has been satisfied
         const int nh = h / factor, nw = w / factor;
         int* heavy_cnt = (int*)(ws + L.heavy_cnt);
         int* list_cnt = heavy_cnt + 1;
@@ -1279,19 +1297,31 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
         const int npatch = (nh - 1) * (nw - 1);
         const int heavy_cap = (int)render_heavy_cap(nh, nw);
         const int mesh_tiles_x = (w + TS - 1) / TS, mesh_ntiles = mesh_tiles_x * ((h + TS - 1) / TS);
-        e = hipMemsetAsync(heavy_cnt, 0, (size_t)n * CNT_STRIDE * sizeof(int), s);
+        e = hipMemsetAsync(heavy_cnt, 0, (size_t)n * CNT_STRIDE * sizeof(int), ms);
         if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: memset: %s", hipGetErrorString(e));
         float* pts_ds = (float*)(ws + L.pts_ds);
-        hipLaunchKernelGGL(mesh_mark_kernel, dim3((npatch + 255) / 256, n), dim3(256), 0, s, boundary_src, src_index, list_cnt, list, npatch, n, h, w, nh, nw,
+        hipLaunchKernelGGL(mesh_mark_kernel, dim3((npatch + 255) / 256, n), dim3(256), 0, ms, boundary_src, src_index, list_cnt, list, npatch, n, h, w, nh, nw,
                            points_src, w2c, pts_ds);
-        hipLaunchKernelGGL(mesh_raster_list_kernel, dim3(256, n), dim3(256), 0, s, (const float*)pts_ds, K, Kinv, tmin, (const int*)list_cnt,
+        hipLaunchKernelGGL(mesh_raster_list_kernel, dim3(256, n), dim3(256), 0, ms, (const float*)pts_ds, K, Kinv, tmin, (const int*)list_cnt,
                            (const int*)list, npatch, n, h, w, nh, nw, 1e-8f, heavy_cnt, heavy, heavy_cap, occ, mesh_ntiles, mesh_tiles_x, epoch);
-        hipLaunchKernelGGL(mesh_raster_heavy_kernel, dim3((h * w + 256 * HEAVY_PX - 1) / (256 * HEAVY_PX), n), dim3(256), 0, s, Kinv, tmin,
+        hipLaunchKernelGGL(mesh_raster_heavy_kernel, dim3((h * w + 256 * HEAVY_PX - 1) / (256 * HEAVY_PX), n), dim3(256), 0, ms, Kinv, tmin,
                            (const int*)heavy_cnt, (const float*)heavy, heavy_cap, n, h, w, 1e-8f, occ, mesh_ntiles, mesh_tiles_x, epoch);
+        if (ms != s) {
+            if (hipEventRecord(ev_join, ms) != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: event record failed");
+        } else if (ev_join) {
+            (void)hipEventDestroy(ev_join);
+            ev_join = nullptr;
+        }
     }
+    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
+                       gmax, n, h, w, group_size, src_index);
     const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
     hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
                        (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
+    if (ev_join) {  // join: the resolve pass applies the occlusion
+        if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: stream wait failed");
+        (void)hipEventDestroy(ev_join);
+    }
     hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
                        depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, tmin, Kinv, (const unsigned*)occ);
     return g3_check_launch("g3_render_items_f32");

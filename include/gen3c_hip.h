@@ -212,7 +212,9 @@ int g3_warp_splat_resolve_f32(const float* image, const float* z, const float* f
  * (n, h, w, group_size) and then reused call after call: the dense out-of-window accumulator inside it is kept all-zero by the kernels
  * themselves (items whose accumulator a launch touched are stamped, and only those are read back and cleared), so no per-call clearing pass;
  * likewise the nearest-hit buffer of the occlusion pass is left at +inf by the resolve pass (per-tile stamps). With foreground masking the
- * occlusion is applied inside the resolve pass (the arithmetic of g3_mesh_occlusion_f32's apply step on the values being written). Limits:
+ * occlusion is applied inside the resolve pass (the arithmetic of g3_mesh_occlusion_f32's apply step on the values being written), and the
+ * marking / rasterising pass runs on a stream the library owns, forked from and joined back into `stream` with events inside this call (all
+ * inputs must be ready on `stream` at call time, as for every entry point; option render_overlap = 0 keeps everything on `stream`). Limits:
  * h < 32766, w < 65534 (packed texel ids); calls that share a workspace must be ordered (same stream). */
 size_t g3_render_workspace_bytes(int n, int h, int w, int group_size);
 int g3_render_workspace_init(void* workspace, int n, int h, int w, int group_size, void* stream);

@@ -17,7 +17,9 @@ t = lambda a: torch.from_numpy(a).to(dev)
 w2cs = torch.eye(4, device=dev).repeat(1, F, 1, 1)
 w2cs[0, :, 0, 3] = torch.linspace(0, 0.3, F, device=dev)
 Ks = t(K)[None, None].expand(1, F, 3, 3).contiguous()
-for fg in (False, True):
+import os
+for fg, overlap in ((False, 1), (True, 1)) + (((True, 0), (True, 1)) if os.environ.get("G3_RENDER_AB") else ()):
+    ops.set_option("render_overlap", overlap)
     cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
                                     input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
     cache.render_cache(w2cs, Ks)
@@ -28,4 +30,4 @@ for fg in (False, True):
         pix, msk = cache.render_cache(w2cs, Ks)
     tm.stop()
     per_item = tm.elapsed_ms() / 3 / F
-    print(f"render 704x1280 foreground_masking={fg}: {per_item:.4f} ms/item = {43.2e6 / (per_item * 1e-3) / 1e9:.0f} GB/s algorithmic; coverage {float(msk.mean()):.3f}", flush=True)
+    print(f"render 704x1280 foreground_masking={fg} occlusion_on_side_stream={overlap}: {per_item:.4f} ms/item = {43.2e6 / (per_item * 1e-3) / 1e9:.0f} GB/s algorithmic; coverage {float(msk.mean()):.3f}", flush=True)
