@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -94,6 +96,17 @@ def _render_workspace(lib, n: int, h: int, w: int, group_size: int, dev, stream)
             _RENDER_WS.pop(next(iter(_RENDER_WS)))
         _RENDER_WS[key] = t
     return t
+
+
+_TWO_STREAM_CHUNKS = os.environ.get("G3_RENDER_TWO_STREAMS", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _render_side_stream(dev) -> "torch.cuda.Stream":
+    s = _SIDE_STREAMS.get(str(dev))
+    if s is None:
+        s = _SIDE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+    return s
 
 
 _WINDOW_SPLAT = True  # False: the two-call form (splat into the global accumulator with atomics, then resolve) - kept for A/B and tests
@@ -297,15 +310,35 @@ class Cache3D_Base:
             bnd_src = memoised(("bnd", id(bm), bm.data_ptr(), _tensor_version(bm), B, F, N, V, H, W), (bm,),
                                lambda: bm.expand(B, F, N, V, 1, H, W).reshape(n_src, H, W).to(torch.uint8).contiguous())
         lib = _lib.load()
-        st = _stream()
-        for i in range(0, m, step):
-            j = min(i + step, m)
+
+        def launch(i, j, st):
             ws = _render_workspace(lib, j - i, H, W, 2, dev, st)
             _lib.check(lib.g3_render_items_f32(_p(pts_src, "points_src"), _p(img_src, "image_src"), _p(msk_src, "mask_src"), _p(bnd_src, "boundary_src", torch.uint8),
                                                _p(src_index[i:j], "src_index", torch.int32), _p(w2cs[i:j], "w2c"), _p(Ks[i:j], "K"),
                                                _p(kinv[i:j], "Kinv") if kinv is not None else 0, ws.data_ptr(), _p(frames[i:j], "frame"),
                                                _p(masks[i:j], "mask"), _p(depths[i:j], "depth") if depths is not None else 0, 0, j - i, n_src, H, W, 2, st),
                        "g3_render_items_f32")
+
+        chunks = [(i, min(i + step, m)) for i in range(0, m, step)]
+        if _TWO_STREAM_CHUNKS and dev.type == "cuda":
+            # every chunk in two halves (whole reference pairs) on two streams: one half's VALU-bound splat next to the other's memory-bound
+            # resolve pass. Each stream has its own workspace (the cache is keyed by stream); the side stream is forked from / joined into the
+            # caller's, so inputs and outputs need no further care.
+            main = torch.cuda.current_stream(dev)
+            side = _render_side_stream(dev)
+            side.wait_stream(main)
+            for (i, j) in chunks:
+                half = ((j - i) // 2 + 1) // 2 * 2
+                if half == 0 or half == j - i:
+                    launch(i, j, main.cuda_stream)
+                    continue
+                launch(i, i + half, main.cuda_stream)
+                with torch.cuda.stream(side):
+                    launch(i + half, j, side.cuda_stream)
+            main.wait_stream(side)
+        else:
+            for (i, j) in chunks:
+                launch(i, j, _stream())
         return (None if render_depth else frames), masks, (depths if render_depth else None)
 
     def input_frame_count(self) -> int:

@@ -20,10 +20,14 @@ cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], in
                                 input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=True, input_format=["B", "C", "H", "W"])
 for _ in range(3):
     cache.render_cache(w2cs, Ks)
+import os
+TWO = os.environ.get("AB") == "two_streams"  # A/B the two-stream chunk halves instead of the side-stream occlusion pass
 res = {0: [], 1: []}
 for rnd in range(4):
     for ov in (0, 1):
-        ops.set_option("render_overlap", ov)
+        renderer._TWO_STREAM_CHUNKS = bool(ov) if TWO else renderer._TWO_STREAM_CHUNKS
+        if not TWO:
+            ops.set_option("render_overlap", ov)
         cache.render_cache(w2cs, Ks)
         torch.cuda.synchronize()
         tm = ops.HipTimer()
@@ -34,4 +38,4 @@ for rnd in range(4):
         res[ov].append(tm.elapsed_ms() / 10 / F)
 for ov in (0, 1):
     v = res[ov]
-    print(f"occlusion pass on a side stream = {ov}: ms/item per round {['%.4f' % x for x in v]}  mean {sum(v) / len(v):.4f} = {43.2e6 / (sum(v) / len(v) * 1e-3) / 1e9:.0f} GB/s")
+    print(f"{'chunk halves on two streams' if TWO else 'occlusion pass on a side stream'} = {ov}: ms/item per round {['%.4f' % x for x in v]}  mean {sum(v) / len(v):.4f} = {43.2e6 / (sum(v) / len(v) * 1e-3) / 1e9:.0f} GB/s")
