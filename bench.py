@@ -92,6 +92,24 @@ def cpu_baseline(threads: int, blocks: int = 1):
                        f"per-block linearity of the extrapolation checked once: profiles/r3_cpu_baseline_linearity.txt")
 
 
+TOK_FIXTURE = ROOT / "tests" / "golden" / "tokenizer_fullsize_samples.npz"
+
+
+def tokenizer_bench_clip(dev, T=121, H=704, W=1280, seed=5):
+    """The fixed-seed 121x704x1280 clip the tokenizer entry encodes (smooth content + noise, generated on the device). The same function
+    feeds tests/test_fullsize_gpu.py::test_tokenizer_full_clip_vs_fp32_oracle, which holds encode / decode of THIS clip against the fp32
+    oracle and wrote the committed samples of the oracle's outputs (TOK_FIXTURE) that `stage_rooflines` compares with."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, max(T // 4, 2), H // 16, W // 16, device=dev, generator=g), size=(T, H, W), mode="trilinear")
+    x = ((base * 2 - 1) * 0.8 + 0.2 * (torch.rand(1, 3, T, H, W, device=dev, generator=g) * 2 - 1)).clamp(-1, 1)
+    return x.to(torch.bfloat16)
+
+
+def tokenizer_sample_index(numel: int, n: int = 8192, seed: int = 11):
+    """Fixed pseudo-random flat positions (host RNG) at which oracle outputs are committed / compared."""
+    return torch.from_numpy(np.random.RandomState(seed).randint(0, numel, size=n).astype(np.int64))
+
+
 def stage_rooflines(dev):
     """The chunk's other two stages at the benchmark size, timed once each with hipEvents (rank 0, N = 1, outside the timed region):
     tokenizer encode / decode of one 121x704x1280 clip (algorithmic work SURVEY.md 8a-a15: 35.7 / 61.3 TFLOP, MFMA-bound) and the cache
@@ -101,9 +119,15 @@ def stage_rooflines(dev):
     out = {}
     net = CausalVideoTokenizerNet(channels=128, device=dev)
     net.init_random(seed=0)
-    x = (torch.rand(1, 3, 121, 704, 1280, device=dev) * 2 - 1).to(torch.bfloat16)
+    net.init_random(seed=3)  # the weights of tests/test_fullsize_gpu.py::test_tokenizer_full_clip_vs_fp32_oracle
+    x = tokenizer_bench_clip(dev)
     z = None
     tok = {}
+    fix = None
+    try:
+        fix = np.load(TOK_FIXTURE)
+    except Exception:
+        pass
     for name, fn, tflop in (("encode", net.encoder, 35.7), ("decode", net.decoder, 61.3)):
         arg = x if name == "encode" else z
         res = fn(arg)  # warm-up (also the decode input)
@@ -113,10 +137,21 @@ def stage_rooflines(dev):
         res = fn(arg)
         tm.stop()
         ms = tm.elapsed_ms()
-        tok[name] = dict(ms=round(ms, 2), achieved=round(tflop / ms * 1e3, 1), frac=round(tflop / ms * 1e3 / PEAK_BF16_TFLOPS, 4))
+        finite = bool(torch.isfinite(res.float()).all())
+        tok[name] = dict(ms=round(ms, 2), achieved=round(tflop / ms * 1e3, 1), frac=round(tflop / ms * 1e3 / PEAK_BF16_TFLOPS, 4), output_finite=finite)
+        if fix is not None:  # the timed result itself against the committed samples of the fp32 oracle's output on this clip / these weights
+            idx = tokenizer_sample_index(res.numel()).to(dev)
+            got = res.reshape(-1)[idx].float().cpu()
+            ref = torch.from_numpy(fix["z_ref" if name == "encode" else "y_ref"])
+            tok[name]["rel_l2_vs_oracle_samples"] = round(float((got - ref).norm() / ref.norm()), 5)
+        if not finite:
+            raise RuntimeError(f"tokenizer {name} of the benchmark clip produced non-finite values")
         if name == "encode":
             z = res
-    out["roofline_tokenizer"] = dict(bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_TFLOPS, workload="CV8x8x8 tokenizer, one 121x704x1280 clip, bf16", **tok)
+    out["roofline_tokenizer"] = dict(bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_TFLOPS, workload="CV8x8x8 tokenizer, one 121x704x1280 clip, bf16",
+                                     parity="rel_l2_vs_oracle_samples: this run's outputs at 8192 fixed positions vs oracle/tokenizer_oracle.py in fp32 on the same clip and weights "
+                                            "(tests/golden/tokenizer_fullsize_samples.npz, written by tests/test_fullsize_gpu.py::test_tokenizer_full_clip_vs_fp32_oracle; "
+                                            "decode here takes this run's own latent, the test the oracle's)" if fix is not None else None, **tok)
     del net, x, z, res
     h, w, F = 704, 1280, 32
     ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=dev), torch.arange(w, dtype=torch.float32, device=dev), indexing="ij")
@@ -172,6 +207,8 @@ def build_parser():
     ap.add_argument("--blocks", type=int, default=28, help="(debug only) number of DiT blocks; anything but 28 is not the benchmark")
     ap.add_argument("--latent", type=str, default="16,88,160", help="(debug only) latent T,H,W")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="A/B: no hipEvent pairs around the launches of the timed region (the roofline / roofline_gemm entries are then null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the tokenizer / renderer roofline entries (a few seconds after the timed region)")
     ap.add_argument("--cp-config", type=str, default="auto",
                     help="N > 1: 'auto' = time the context-parallel configurations (head groups x attention kernel x collective schedule) on a few blocks "
@@ -200,37 +237,142 @@ def cp_report(cpa, self_attn, gemms, steps: int, rccl_ranks: int) -> dict:
 
 
 CP_TUNE_BLOCKS = 4  # DiT blocks per autotune forward (every block has the same shapes and collectives)
+CP_FALLBACK = (4, "auto", "gather_first")  # ContextParallelAttention's own default: what runs when the autotune has nothing to offer
+DIST_TIMEOUT_S = int(os.environ.get("G3_BENCH_DIST_TIMEOUT_S", "420"))  # process-group timeout of the N > 1 run (parallel.init_distributed)
+PHASE_DEADLINE_S = {"init": 400, "autotune": 240, "timed": 360}  # watchdog: a phase that overruns ends the run WITH a JSON line
 
 
-def autotune_cp(net, den, xt, cond, uncond, dev, dist):
+def _injected(phase: str, rank: int, cand=None) -> bool:
+    """Test hook (tests/test_cp_gpu.py): G3_BENCH_INJECT="autotune:4,w4b,local_first:1" raises inside that candidate on rank 1,
+    "timed:1" raises in the timed region on rank 1. Never set by the driver."""
+    spec = os.environ.get("G3_BENCH_INJECT", "")
+    if not spec:
+        return False
+    parts = spec.split(":")
+    if parts[0] != phase or int(parts[-1]) != rank:
+        return False
+    return phase != "autotune" or ",".join(str(c) for c in cand) == parts[1]
+
+
+def autotune_cp(net, den, xt, cond, uncond, dev, dist, rank: int = 0, progress: dict | None = None):
     """Pick (head_groups, attention kernel, collective schedule) of ContextParallelAttention by measurement: the driver's multi-GPU run is the
     only one this code ever gets on real xGMI links, so it tunes itself. Every candidate runs the same denoise step on the first CP_TUNE_BLOCKS
     blocks (1 untimed + 1 timed, barrier + synchronize on both sides); ranks agree on each time via all_reduce(MAX), so every rank picks the
-    same winner. Untimed by the benchmark (before the warm-up steps); the state `xt` is not advanced."""
+    same winner. Untimed by the benchmark (before the warm-up steps); the state `xt` is not advanced.
+
+    A candidate that RAISES on any rank is dropped on every rank (the same all_reduce carries a failure flag) and listed in the returned
+    `failed`; if nothing survives, CP_FALLBACK is configured. Returns (best or None, table, failed)."""
     cands = [(G, kern, sched) for sched in ("gather_first", "local_first") for kern in ("w4b", "wave8") for G in (1, 2, 4, 8)]
     cpa = net._cp_attn
     net._tune_blocks = CP_TUNE_BLOCKS
-    table = []
+    table, failed = [], []
     try:
-        for (G, kern, sched) in cands:
-            cpa.configure(head_groups=G, kernel=kern, schedule=sched)
-            ms = []
-            for rep in range(2):
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                den.denoise_step(xt, 0, cond, uncond, 1.0, 0.001, 1)
-                torch.cuda.synchronize()
-                ms.append((time.perf_counter() - t0) * 1e3)
-            t = torch.tensor([ms[1]], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            table.append(dict(head_groups=G, kernel=kern, schedule=sched, ms=round(float(t.item()), 3)))
+        for cand in cands:
+            (G, kern, sched) = cand
+            if progress is not None:
+                progress.update(candidate=cand, table=table, failed=failed)
+            ms, err = [0.0, 0.0], None
+            try:
+                if _injected("autotune", rank, cand):
+                    raise RuntimeError(f"injected failure in candidate {cand} on rank {rank}")
+                cpa.configure(head_groups=G, kernel=kern, schedule=sched)
+                ms = []
+                for rep in range(2):
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    den.denoise_step(xt, 0, cond, uncond, 1.0, 0.001, 1)
+                    torch.cuda.synchronize()
+                    ms.append((time.perf_counter() - t0) * 1e3)
+            except Exception as e:  # this rank cannot run the candidate: tell the others through the agreement below
+                err = repr(e)
+            t = torch.tensor([ms[1] if err is None else 0.0, 0.0 if err is None else 1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # [slowest rank's time, 1 if any rank failed]
+            eff = getattr(cpa, "effective", None) or {}
+            if float(t[1].item()) > 0:
+                failed.append(dict(head_groups=G, kernel=kern, schedule=sched, error=err or "failed on another rank"))
+                continue
+            table.append(dict(head_groups=G, kernel=kern, schedule=sched, ms=round(float(t[0].item()), 3),
+                              ran=dict(kernel=eff.get("kernel", kern), schedule=eff.get("schedule", sched), head_groups=eff.get("head_groups", G))))
     finally:
         net._tune_blocks = None
+    if not table:
+        cpa.configure(head_groups=CP_FALLBACK[0], kernel=CP_FALLBACK[1], schedule=CP_FALLBACK[2])
+        return None, table, failed
     best = min(table, key=lambda r: r["ms"])
     cpa.configure(head_groups=best["head_groups"], kernel=best["kernel"], schedule=best["schedule"])
-    return best, table
+    return best, table, failed
 
+
+class RunGuard:
+    """The one multi-GPU run the driver makes must end with a JSON line whatever happens. One daemon thread per rank (N > 1 only):
+      * a rank whose phase raised publishes the exception in the process group's key-value store (`fail`); every rank's thread polls the
+        store, so rank 0 learns of a failure on rank 5 without a collective;
+      * a phase that overruns its deadline (a hung collective: no Python exception ever surfaces) trips the same path;
+    then rank 0 prints a line with `value: null`, the phase, what was known (`progress`: autotune candidate / table so far) and the error,
+    and every rank leaves with os._exit(1) - before the process-group timeout (DIST_TIMEOUT_S) lets the NCCL watchdog abort silently."""
+    KEY = "g3_bench_error"
+
+    def __init__(self, rank: int, world: int, base_line: dict):
+        import threading
+        self.rank, self.world, self.base = rank, world, dict(base_line)
+        self.phase, self.deadline, self.progress, self.done = "init", time.monotonic() + PHASE_DEADLINE_S["init"], {}, False
+        self.store, self._lock, self._emitted = None, threading.Lock(), False
+        try:
+            from torch.distributed.distributed_c10d import _get_default_store
+            self.store = _get_default_store()
+        except Exception:
+            pass
+        self._t = threading.Thread(target=self._watch, daemon=True)
+        self._t.start()
+
+    def enter(self, phase: str, seconds: float | None = None):
+        self.phase, self.deadline = phase, time.monotonic() + (seconds if seconds is not None else PHASE_DEADLINE_S.get(phase, 300))
+
+    def finish(self):
+        self.done = True
+
+    def fail(self, where: str, exc: BaseException):
+        """Called by the rank whose phase raised: publish, then let the watcher threads end the run (rank 0 prints)."""
+        msg = f"rank {self.rank} in {where}: {exc!r}"
+        print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+        try:
+            if self.store is not None:
+                self.store.set(self.KEY, msg)
+        except Exception:
+            pass
+        if self.rank == 0:
+            self._emit(msg)
+        time.sleep(15)  # rank 0's watcher prints within its poll interval; then leave (torchrun ends the other ranks)
+        os._exit(1)
+
+    def _emit(self, error: str):
+        with self._lock:
+            if self._emitted:
+                time.sleep(30)  # the other thread is printing / leaving
+            self._emitted = True
+        line = dict(self.base)
+        prog = {k: v for k, v in self.progress.items()}
+        line.update(value=None, ms_per_step=None, error=error, failed_phase=self.phase, progress=prog)
+        print(json.dumps(line, default=str), flush=True)
+        os._exit(1)
+
+    def _watch(self):
+        while not self.done:
+            time.sleep(1.0)
+            err = None
+            try:
+                if self.store is not None and self.store.check([self.KEY]):
+                    err = self.store.get(self.KEY).decode()
+            except Exception:
+                pass
+            if err is None and time.monotonic() > self.deadline:
+                err = f"rank {self.rank}: phase '{self.phase}' exceeded its {PHASE_DEADLINE_S.get(self.phase, 300)} s deadline (hung collective?)"
+            if err is not None and not self.done:
+                if self.rank == 0:
+                    self._emit(err)
+                time.sleep(5)
+                os._exit(1)
 
 
 def main():
@@ -257,7 +399,7 @@ def main():
     if world > 1:
         # G3_BENCH_BACKEND=gloo + G3_BENCH_SHARE_GPU=1: plumbing check of this script's N>1 path on a 1-GPU box (all ranks on
         # cuda:0, collectives over gloo); not a measurement. The driver's runs use the defaults: RCCL, one GPU per rank.
-        local = init_distributed(os.environ.get("G3_BENCH_BACKEND", "nccl"))
+        local = init_distributed(os.environ.get("G3_BENCH_BACKEND", "nccl"), timeout_s=DIST_TIMEOUT_S)
         if os.environ.get("G3_BENCH_SHARE_GPU") == "1":
             local = 0
         elif torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
@@ -271,11 +413,43 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     T, Hl, Wl = (int(v) for v in args.latent.split(","))
-    net = VideoExtendGeneralDIT(in_channels=16 + 16 * 4 + 1, rope_t_extrapolation_ratio=2.0, num_blocks=args.blocks,
-                                device=dev, init_weights=False)
-    net.initialize_weights(randomize_adaln=True, seed=1234)  # same weights on every rank
-    if world > 1:
-        net.enable_context_parallel(parallel_state.get_context_parallel_group())
+    N_tok = T * (Hl // 2) * (Wl // 2)
+    step_flops = 2 * dit_forward_flops(N_tok, L=args.blocks)
+    base_line = {
+        "metric": "denoise-steps/sec (121x1280x704 latent, Cosmos-7B)", "value": None, "unit": "denoise-steps/sec",
+        "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"GEN3C-Cosmos-7B denoise step: 2 DiT forwards (cond+uncond) + CFG + latent replace + Euler on latent "
+                               f"[1,16,{T},{Hl},{Wl}] = {N_tok} tokens, {args.blocks} blocks x 4096, 32 heads, guidance=1, 35-step Karras schedule, "
+                               f"random-init weights", "parallelism": f"cp{world}" if world > 1 else "single-gpu",
+                   "step_pflop": round(step_flops / 1e15, 4)},
+    }
+    # N > 1: from here on the run ends with a JSON line whatever happens (exception on any rank, hung collective) - see RunGuard
+    guard = RunGuard(rank, world, base_line) if world > 1 else None
+
+    def guarded(phase, fn):
+        if guard is not None:
+            guard.enter(phase)
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001 - whatever it is, the line must still be printed
+            if guard is not None:
+                guard.fail(phase, e)
+            line = dict(base_line)
+            line.update(error=repr(e), failed_phase=phase)
+            print(json.dumps(line), flush=True)
+            sys.exit(1)
+
+    def setup():
+        net = VideoExtendGeneralDIT(in_channels=16 + 16 * 4 + 1, rope_t_extrapolation_ratio=2.0, num_blocks=args.blocks,
+                                    device=dev, init_weights=False)
+        net.initialize_weights(randomize_adaln=True, seed=1234)  # same weights on every rank
+        if world > 1:
+            net.enable_context_parallel(parallel_state.get_context_parallel_group())
+        return net
+
+    net = guarded("init", setup)
 
     # ---- synthetic inputs, identical on every rank (host RNG), resident in HBM before timing
     rs = np.random.RandomState(1)
@@ -308,40 +482,69 @@ def main():
 
     cp_info = None
     if world > 1:
-        if args.cp_config == "auto":
-            best, table = autotune_cp(net, den, xt, cond, uncond, dev, dist)
-            cp_info = dict(chosen=best, autotune_blocks=CP_TUNE_BLOCKS, autotune_ms=table)
-        else:
+        def tune():
+            if args.cp_config == "auto":
+                best, table, failed = autotune_cp(net, den, xt, cond, uncond, dev, dist, rank=rank, progress=guard.progress)
+                info = dict(chosen=best if best is not None else dict(head_groups=CP_FALLBACK[0], kernel=CP_FALLBACK[1], schedule=CP_FALLBACK[2], ms=None),
+                            autotune_blocks=CP_TUNE_BLOCKS, autotune_ms=table)
+                if failed:
+                    info["autotune_failed"] = failed
+                if best is None:
+                    info["autotune_error"] = "no candidate survived on every rank: running the fixed fallback configuration"
+                return info
             G, kern, sched = args.cp_config.split(",")
             net._cp_attn.configure(head_groups=int(G), kernel=kern, schedule=sched)
-            cp_info = dict(chosen=dict(head_groups=int(G), kernel=kern, schedule=sched), autotune_ms=None)
+            return dict(chosen=dict(head_groups=int(G), kernel=kern, schedule=sched), autotune_ms=None)
+        cp_info = guarded("autotune", tune)
+        guard.progress.clear()
+        guard.progress.update(cp=cp_info)
 
-    step_id = 0
-    for _ in range(args.warmup):
-        xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
-        step_id += 1
-    barrier()
-    ops.enable_kernel_timers(True)
-    if world > 1:
-        net._cp_attn.stats = []
-        net._cp_attn.bytes_gathered = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        xt = den.denoise_step(xt, step_id, cond, uncond, 1.0, 0.001, 1)
-        step_id += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
+    state = dict(xt=xt, step_id=0)
+
+    def timed_region():
+        xt_, step_id = state["xt"], 0
+        for _ in range(args.warmup):
+            xt_ = den.denoise_step(xt_, step_id, cond, uncond, 1.0, 0.001, 1)
+            step_id += 1
+        barrier()
+        ops.enable_kernel_timers(not args.no_kernel_timers)
+        if world > 1:
+            net._cp_attn.stats = []
+            net._cp_attn.bytes_gathered = 0
+        if _injected("timed", rank):
+            raise RuntimeError(f"injected failure in the timed region on rank {rank}")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            xt_ = den.denoise_step(xt_, step_id, cond, uncond, 1.0, 0.001, 1)
+            step_id += 1
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's own time to finish its K steps (before the closing barrier): load imbalance shows here
+        barrier()
+        elapsed_ = time.perf_counter() - t0
+        state["xt"] = xt_
+        return elapsed_, own
+
+    elapsed, own_elapsed = guarded("timed", timed_region)
+    xt = state["xt"]
     timers = ops.collected_kernel_timers()
     ops.enable_kernel_timers(False)
     finite = bool(torch.isfinite(xt.float()).all())
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    rank_ms = None
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        def reduce_times():
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mine = torch.tensor([own_elapsed / args.steps * 1e3], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            return [round(float(t.item()), 2) for t in allr]
+        rank_ms = guarded("timed", reduce_times)
     elapsed = float(tmax.item())
 
     # ---- dominant kernel: self-attention flash-attention forward, timed live with hipEvents on its launch stream
-    N_tok = T * (Hl // 2) * (Wl // 2)
+    if guard is not None:
+        guard.enter("report", 120)
     self_attn = [(meta, tm.elapsed_ms()) for (name, meta, tm) in timers if name == "flash_attn_fwd" and meta["Skv"] > 2048]
     roof = None
     if self_attn:
@@ -383,25 +586,23 @@ def main():
         cp_info.update(cp_report(net._cp_attn, self_attn, gemms, args.steps, dist.get_world_size() if dist.get_backend() == "nccl" else 0))
         net._cp_attn.stats = None
 
+    if world > 1:
+        cp_info["rank_own_ms_per_step"] = dict(min=min(rank_ms), max=max(rank_ms), per_rank=rank_ms,
+                                               note="each rank's own wall time per step up to ITS synchronize, before the closing barrier")
+        guard.finish()
     if rank == 0:
-        step_flops = 2 * dit_forward_flops(N_tok, L=args.blocks)
         ms_per_step = elapsed / args.steps * 1e3
         value = args.steps / elapsed
-        out = {
-            "metric": "denoise-steps/sec (121x1280x704 latent, Cosmos-7B)", "value": round(value, 5), "unit": "denoise-steps/sec",
-            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"GEN3C-Cosmos-7B denoise step: 2 DiT forwards (cond+uncond) + CFG + latent replace + Euler on latent "
-                                   f"[1,16,{T},{Hl},{Wl}] = {N_tok} tokens, {args.blocks} blocks x 4096, 32 heads, guidance=1, 35-step Karras schedule, "
-                                   f"random-init weights", "parallelism": f"cp{world}" if world > 1 else "single-gpu",
-                       "step_pflop": round(step_flops / 1e15, 4)},
+        out = dict(base_line)
+        out.update({
+            "value": round(value, 5), "ms_per_step": round(ms_per_step, 2),
             "step_tflops_per_gpu": round(step_flops / (elapsed / args.steps) / 1e12 / world, 1),
             "step_mfma_frac": round(step_flops / (elapsed / args.steps) / 1e12 / world / PEAK_BF16_TFLOPS, 4),
             "output_finite": finite,
+            "kernel_timers": not args.no_kernel_timers,
             "roofline": roof,
             "roofline_gemm": roof_gemm,
-        }
+        })
         if cp_info is not None:
             out["cp"] = cp_info
         if not args.no_extras and world == 1:

@@ -115,7 +115,7 @@ class _ParallelState:
 parallel_state = _ParallelState()
 
 
-def init_distributed(backend: Optional[str] = None) -> int:
+def init_distributed(backend: Optional[str] = None, timeout_s: Optional[int] = None) -> int:
     """Counterpart of cosmos_predict1.utils.distributed.init (utils/distributed.py:49-79) without the NVIDIA-only
     parts (pynvml affinity, libcudart cudaDeviceSetLimit). One process per GPU; rendezvous via env:// as set by
     torchrun. Returns the local device index."""
@@ -127,7 +127,8 @@ def init_distributed(backend: Optional[str] = None) -> int:
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        timeout = timedelta(seconds=int(os.getenv("TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC", 1800)))
+        # timeout_s: bench.py passes a short collective timeout - a hung exchange must end the run inside the driver's budget, not after 30 min
+        timeout = timedelta(seconds=int(timeout_s if timeout_s is not None else os.getenv("TORCH_NCCL_HEARTBEAT_TIMEOUT_SEC", 1800)))
         dist.init_process_group(backend=backend, init_method="env://", timeout=timeout)
     return local_rank
 
@@ -225,6 +226,7 @@ class ContextParallelAttention:
         self.schedule = schedule
         self.kernel = kernel
         self.stats = None
+        self.effective = None  # set by finish(): dict(schedule, kernel, head_groups) of the configuration that actually ran
         self.bytes_gathered = 0  # received from the other ranks since construction / the last reset (bench.py's "cp" object)
 
     def configure(self, head_groups: Optional[int] = None, schedule: Optional[str] = None, kernel: Optional[str] = None):
@@ -306,6 +308,10 @@ class ContextParallelAttention:
         works = pending["works"]
         variant = self._variant(S_local, S_all, B, pending["H"]) if q.is_cuda else 0
         local_first = self.schedule == "local_first" and pending["segmented"] and self.world > 1 and "attention_partial" in be
+        # what this layer actually runs (a requested "local_first" needs segmented V^T and a split-KV backend; a forced one-wave kernel needs
+        # S_all % 64 == 0): read by bench.py so that its autotune table and `cp.chosen` never label a fallback with the requested name
+        self.effective = dict(schedule="local_first" if local_first else "gather_first", kernel={11: "w4b", 4: "wave8"}.get(variant, str(variant)),
+                              head_groups=len(pending["works"]))
         two_streams = q.is_cuda and len(works) >= 2
         main = side = q_ready = None
         if two_streams:

@@ -35,6 +35,8 @@ def causal_conv3d(x: torch.Tensor, sd: SD, pre: str, stride=(1, 1, 1), spatial_p
         x = torch.cat([x[:, :, :1].repeat(1, 1, time_pad, 1, 1), x], dim=2)
     if spatial_pad:
         x = F.pad(x, (spatial_pad,) * 4 + (0, 0))
+    if CONV_IMPL == "taps":
+        return _conv3d_taps(x, w, b, stride)
     return F.conv3d(x, w, b, stride=stride)
 
 
@@ -198,3 +200,29 @@ def encode(sd: SD, state: torch.Tensor, latent_mean: torch.Tensor, latent_std: t
 def decode(sd: SD, latent: torch.Tensor, latent_mean: torch.Tensor, latent_std: torch.Tensor) -> torch.Tensor:
     """VideoJITTokenizer.decode for one chunk (pretrained_vae.py:144-152)."""
     return decoder(sd, latent * latent_std + latent_mean)
+
+
+# ---- convolution back end of the oracle ---------------------------------------------------------------------------------------------
+# "torch": F.conv3d (the form the golden fixtures pin). "taps": the same convolution written as one matmul per kernel tap over shifted
+# views of the padded input - for the full-size on-device evaluation (tests/test_fullsize_gpu.py), where the vendor's fp32 conv3d may
+# fall back to a naive kernel. tests/test_tokenizer_oracle_golden.py holds "taps" against "torch" on every geometry of the network.
+CONV_IMPL = "torch"
+
+
+def _conv3d_taps(x: torch.Tensor, w: torch.Tensor, b, stride) -> torch.Tensor:
+    """x [B,Cin,T,H,W] (already padded), w [Cout,Cin,kt,kh,kw] -> [B,Cout,To,Ho,Wo]; out = sum over taps of x_shift @ w_tap^T."""
+    B, Cin, T, H, W = x.shape
+    Cout, _, kt, kh, kw = w.shape
+    st, sh, sw = stride
+    To, Ho, Wo = (T - kt) // st + 1, (H - kh) // sh + 1, (W - kw) // sw + 1
+    xl = x.permute(0, 2, 3, 4, 1).contiguous()  # channels last
+    out = None
+    for a in range(kt):
+        for i in range(kh):
+            for j in range(kw):
+                v = xl[:, a:a + (To - 1) * st + 1:st, i:i + (Ho - 1) * sh + 1:sh, j:j + (Wo - 1) * sw + 1:sw]
+                y = torch.matmul(v.reshape(-1, Cin), w[:, :, a, i, j].t())
+                out = y if out is None else out.add_(y)
+    if b is not None:
+        out = out + b
+    return out.view(B, To, Ho, Wo, Cout).permute(0, 4, 1, 2, 3)

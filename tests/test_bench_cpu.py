@@ -101,8 +101,8 @@ def test_cp_autotune_picks_the_fastest_candidate_and_reports(monkeypatch):
 
     monkeypatch.setattr(bench.time, "perf_counter", fake_perf_counter)
     monkeypatch.setattr(torch.cuda, "synchronize", fake_sync)
-    best, table = bench.autotune_cp(net, FakeDen(), None, None, None, torch.device("cpu"), FakeDist)
-    assert len(table) == 16 and {r["schedule"] for r in table} == {"gather_first", "local_first"} and {r["head_groups"] for r in table} == {1, 2, 4, 8}
+    best, table, failed = bench.autotune_cp(net, FakeDen(), None, None, None, torch.device("cpu"), FakeDist)
+    assert failed == [] and len(table) == 16 and {r["schedule"] for r in table} == {"gather_first", "local_first"} and {r["head_groups"] for r in table} == {1, 2, 4, 8}
     assert (best["head_groups"], best["kernel"], best["schedule"]) == (2, "w4b", "local_first")
     assert net._cp_attn.cfg == (2, "w4b", "local_first") and net._tune_blocks is None and FakeDist.reduced == 16
 
@@ -120,3 +120,92 @@ def test_cp_autotune_picks_the_fastest_candidate_and_reports(monkeypatch):
         assert key in rep, key
     assert rep["exposed_collective_wait_ms_per_step"] == 0.6 and rep["attention_ms_per_step"] == 20.0 and rep["gemm_ms_per_step"] == 12.0
     assert rep["gathered_bytes_per_step"] == 12345678 // 2 and rep["worst_single_wait_ms"] == 0.5
+
+
+def _autotune_fakes(monkeypatch, fail_on=None, fail_everything=False):
+    import torch
+    import bench
+
+    class FakeCPA:
+        def __init__(self):
+            self.cfg, self.stats, self.bytes_gathered, self.effective = None, [], 0, None
+
+        def configure(self, head_groups=None, kernel=None, schedule=None):
+            self.cfg = (head_groups, kernel, schedule)
+
+    class FakeNet:
+        def __init__(self):
+            self._cp_attn, self._tune_blocks = FakeCPA(), None
+
+    class FakeDist:
+        class ReduceOp:
+            MAX = "max"
+
+        @staticmethod
+        def barrier():
+            pass
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            pass
+
+    net = FakeNet()
+
+    class FakeDen:
+        def denoise_step(self, xt, step, c, u, g, aug, seed):
+            if fail_everything or net._cp_attn.cfg == fail_on:
+                raise RuntimeError("HIP error: invalid configuration argument")
+            net._cp_attn.effective = dict(schedule="gather_first", kernel="wave8", head_groups=net._cp_attn.cfg[0])  # e.g. a silent fallback
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda: None)
+    return bench, net, FakeDen(), FakeDist
+
+
+def test_cp_autotune_drops_a_raising_candidate_and_keeps_going(monkeypatch):
+    """one raising candidate must not cost the run. It is dropped (and listed), the others are still timed, the table says what each
+    candidate actually RAN (ContextParallelAttention.effective - ADVICE r3: a requested local_first / w4b may fall back silently)."""
+    import torch
+    bench, net, den, fdist = _autotune_fakes(monkeypatch, fail_on=(8, "wave8", "local_first"))
+    progress = {}
+    best, table, failed = bench.autotune_cp(net, den, None, None, None, torch.device("cpu"), fdist, rank=0, progress=progress)
+    assert len(table) == 15 and len(failed) == 1
+    assert (failed[0]["head_groups"], failed[0]["kernel"], failed[0]["schedule"]) == (8, "wave8", "local_first") and "invalid configuration" in failed[0]["error"]
+    assert best is not None and net._tune_blocks is None
+    assert all(r["ran"] == dict(kernel="wave8", schedule="gather_first", head_groups=r["head_groups"]) for r in table)
+    assert progress["candidate"] == (8, "wave8", "local_first")  # the watchdog's line would name the last candidate entered
+
+
+def test_cp_autotune_with_no_survivor_configures_the_fixed_fallback(monkeypatch):
+    import torch
+    bench, net, den, fdist = _autotune_fakes(monkeypatch, fail_everything=True)
+    best, table, failed = bench.autotune_cp(net, den, None, None, None, torch.device("cpu"), fdist)
+    assert best is None and table == [] and len(failed) == 16
+    assert net._cp_attn.cfg == bench.CP_FALLBACK and net._tune_blocks is None
+
+
+def test_injection_hook_parses(monkeypatch):
+    import bench
+    monkeypatch.setenv("G3_BENCH_INJECT", "autotune:4,w4b,local_first:1")
+    assert bench._injected("autotune", 1, (4, "w4b", "local_first")) and not bench._injected("autotune", 0, (4, "w4b", "local_first"))
+    assert not bench._injected("autotune", 1, (2, "w4b", "local_first")) and not bench._injected("timed", 1)
+    monkeypatch.setenv("G3_BENCH_INJECT", "timed:1")
+    assert bench._injected("timed", 1) and not bench._injected("timed", 0)
+    monkeypatch.delenv("G3_BENCH_INJECT")
+    assert not bench._injected("timed", 1)
+
+
+def test_run_guard_prints_a_null_value_line_when_a_phase_overruns():
+    """RunGuard in a child process: no process group (store = None), a 'timed' phase with a 1 s deadline that never finishes -> rank 0 prints a
+    JSON line with value null, the phase and the progress it was given, and the process leaves with code 1."""
+    import json
+    code = (
+        "import sys, time; sys.path.insert(0, %r); import bench\n"
+        "g = bench.RunGuard(0, 8, {'metric': 'm', 'value': None, 'n_gpus': 8})\n"
+        "g.progress.update(candidate=(4, 'w4b', 'local_first'))\n"
+        "g.enter('timed', 1.0)\n"
+        "time.sleep(30)\n" % str(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["value"] is None and line["n_gpus"] == 8 and line["failed_phase"] == "timed" and "deadline" in line["error"]
+    assert line["progress"]["candidate"] == [4, "w4b", "local_first"]

@@ -109,3 +109,48 @@ def test_bench_multi_gpu_path_autotunes_and_prints_cp_object():
     # 4 blocks x (K + V shard of the other rank): 2 forwards batched as B = 2 -> rows = 384 * 2, 4096 features, bf16
     assert cp["gathered_bytes_per_step"] == 4 * 2 * (384 * 2 * 4096 * 2)
     print(json.dumps(cp)[:1500])
+
+
+def _run_bench_share(extra_env, timeout=900):
+    import os
+    env = dict(os.environ, G3_BENCH_BACKEND="gloo", G3_BENCH_SHARE_GPU="1", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--blocks", "4", "--latent", "8,16,24",
+           "--no-cpu-baseline", "--no-extras"]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT), env=env)
+
+
+def test_bench_multi_gpu_survives_a_failing_autotune_candidate():
+    """candidate (4, w4b, local_first) raises on rank 1 only - both ranks must drop it together (the failure flag rides on the
+    agreement all_reduce), finish the autotune on the other 15, run the timed region and print the normal line, with the casualty listed."""
+    import json
+    r = _run_bench_share({"G3_BENCH_INJECT": "autotune:4,w4b,local_first:1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cp = out["cp"]
+    assert out["value"] is not None and out["output_finite"] and len(cp["autotune_ms"]) == 15
+    assert [(f["head_groups"], f["kernel"], f["schedule"]) for f in cp["autotune_failed"]] == [(4, "w4b", "local_first")]
+    assert all("ran" in row for row in cp["autotune_ms"])
+    rk = cp["rank_own_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] <= rk["max"]
+    print(json.dumps(cp["autotune_failed"]), json.dumps(rk))
+
+
+def test_bench_multi_gpu_prints_a_null_line_when_the_timed_region_fails_on_another_rank():
+    """Rank 1 raises inside the timed region (rank 0 is then stuck in a collective): rank 0 must still print ONE JSON line - value null, the
+    phase, the chosen configuration, rank 1's exception (delivered through the process group's key-value store) - and the run must end at once
+    with a non-zero exit code, not after the process-group timeout."""
+    import json
+    import time
+    t0 = time.time()
+    r = _run_bench_share({"G3_BENCH_INJECT": "timed:1"}, timeout=600)
+    took = time.time() - t0
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert out["value"] is None and out["n_gpus"] == 2 and out["failed_phase"] == "timed"
+    assert "rank 1" in out["error"] and "injected failure" in out["error"]
+    assert out["progress"]["cp"]["chosen"]["head_groups"] in (1, 2, 4, 8)
+    assert took < 300, f"the failed run took {took:.0f} s to end"

@@ -4,6 +4,8 @@ that do not need the (far too slow) CPU oracle at this size:
   * permutation invariance of attention over the key/value tokens;
   * linearity of the GEMM in its token rows (row subsets give the same rows)."""
 import math
+import os
+from pathlib import Path
 
 import pytest
 import torch
@@ -190,3 +192,73 @@ def test_dit_full_size_single_block_vs_fp32_oracle():
     mx = float((y.float() - y_ref).abs().max())
     print(f"[dit D=4096 H=32, 1 block, 56320 tokens (full size)] rel_l2={rel:.3e} max_abs={mx:.3e} ref_absmax={float(y_ref.abs().max()):.3e}")
     assert rel <= 9e-3 and mx <= 1.5e-2 * float(y_ref.abs().max())  # measured 5.87e-3 / 6.7e-3 of max|y|
+
+
+def _oracle_conv_impl(dev):
+    """The vendor's fp32 conv3d may fall back to a naive kernel at these sizes: probe one 256 -> 256 (1,3,3) convolution on a
+    31 x 176 x 320 tensor and switch the oracle to its per-tap matmul form (equal to F.conv3d: tests/test_tokenizer_oracle_golden.py) if slow."""
+    import time
+    x = torch.randn(1, 256, 31, 176, 320, device=dev)
+    w = torch.randn(256, 256, 1, 3, 3, device=dev) * 0.02
+    try:
+        torch.nn.functional.conv3d(x[:, :, :2], w)  # (first call: kernel selection / compilation)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        torch.nn.functional.conv3d(x, w)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    except RuntimeError:
+        dt = float("inf")
+    return ("torch" if dt < 2.0 else "taps"), dt
+
+
+def test_tokenizer_full_clip_vs_fp32_oracle():
+    """the ONE tokenizer configuration bench.py times - channels = 128 (256 / 512-wide levels), one 121 x 704 x 1280 clip, encode and
+    decode (tokenizer/modules/layers3d.py:669-949, diffusion/module/pretrained_vae.py:342-359) - against oracle/tokenizer_oracle.py evaluated in
+    fp32 on the same device (the oracle is plain torch). At this size the 512-channel activations are 1.79 GB (byte offsets within 17 % of 2^31), the
+    spatial attention's 16 frames alternate over two streams with per-stream 14 080 x 14 080 score buffers, GroupNorm statistics arrive from the
+    producing convolutions' epilogues through fp64 atomics and the causal temporal attention sees all 16 latent frames. The error is reported PER
+    LATENT FRAME (and, for the reconstruction, per group of 8 pixel frames) so that a fault in the temporal chain cannot hide in the mean."""
+    from gen3c_amd.tokenizer import CausalVideoTokenizerNet
+    from oracle import tokenizer_oracle as tok
+    dev = torch.device("cuda:0")
+    net = CausalVideoTokenizerNet(channels=128, device=dev)
+    sd = net.init_random(seed=3)
+    sd32 = {k: v.to(torch.bfloat16).float().to(dev) for k, v in sd.items()}
+    import bench
+    x = bench.tokenizer_bench_clip(dev)
+    z = net.encoder(x)
+    torch.cuda.synchronize()
+    assert z.shape == (1, 16, 16, 88, 160) and torch.isfinite(z.float()).all()
+    z2 = net.encoder(x)  # a second pass through the cached streams / buffers: same input, same latent (up to the order of the fp64 statistics atomics)
+    torch.cuda.synchronize()
+    rr = _rel_l2(z2, z)
+    assert rr < 1e-3, f"two encodes of the same clip differ by rel-L2 {rr:.3e}"
+    impl, probe_s = _oracle_conv_impl(dev)
+    tok.CONV_IMPL = impl
+    try:
+        with torch.no_grad():
+            z_ref = tok.encoder(sd32, x.float())
+            zin = z_ref.to(torch.bfloat16)
+            y_ref = tok.decoder(sd32, zin.float())
+    finally:
+        tok.CONV_IMPL = "torch"
+    y = net.decoder(zin)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 121, 704, 1280) and torch.isfinite(y.float()).all()
+    rz, ry = _rel_l2(z, z_ref), _rel_l2(y, y_ref)
+    per_z = [_rel_l2(z[:, :, t], z_ref[:, :, t]) for t in range(16)]
+    groups = [slice(0, 1)] + [slice(1 + 8 * i, 9 + 8 * i) for i in range(15)]
+    per_y = [_rel_l2(y[:, :, s_], y_ref[:, :, s_]) for s_ in groups]
+    print(f"[tokenizer ch128 121x704x1280 (bench size), oracle conv = {impl} ({probe_s:.2f}s probe)] encoder rel_l2={rz:.3e} decoder rel_l2={ry:.3e} re-encode={rr:.1e}")
+    print("  per latent frame, encoder: " + " ".join(f"{v:.2e}" for v in per_z))
+    print("  per latent frame, decoder: " + " ".join(f"{v:.2e}" for v in per_y))
+    if os.environ.get("G3_WRITE_FULLSIZE_FIXTURE"):  # samples of the oracle's outputs for bench.py's parity entry (copied to tests/golden/ by hand)
+        import numpy as np
+        with torch.no_grad():  # bench.py decodes ITS OWN latent: commit the oracle's reconstruction of the oracle's latent (what the product should approach)
+            out = Path(os.environ["G3_WRITE_FULLSIZE_FIXTURE"])
+            out.parent.mkdir(parents=True, exist_ok=True)
+            np.savez(out, z_ref=z_ref.reshape(-1)[bench.tokenizer_sample_index(z_ref.numel()).to(dev)].cpu().numpy(),
+                     y_ref=y_ref.reshape(-1)[bench.tokenizer_sample_index(y_ref.numel()).to(dev)].cpu().numpy())
+    assert rz <= 1.5e-2 and ry <= 1.8e-2  # 17x352x640 / 9x704x1280 clips measure 7.0e-3 / 9.2e-3
+    assert max(per_z) <= 2.5e-2 and max(per_y) <= 3.0e-2, "one latent frame is off: temporal chain / stream hand-off"
