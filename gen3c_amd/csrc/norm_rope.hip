@@ -136,10 +136,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restr
 // cos/sin tables are fp32 [S][128] (row = sequence position, shared by all batches/heads); nullptr = no RoPE.
 // One thread owns 8 dims of the first half and the matching 8 of the second half; 8 threads per head.
 // ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(const bf16_t* __restrict__ in, int64_t ld_in,
+// `in` and `out` are NOT __restrict__: the DiT runs this kernel IN PLACE on the q | k columns of the fused QKV buffer (out == in,
+// gen3c_amd/dit.py). That is sound because a thread reads exactly the 16 elements it later writes (its own 8-element slices of the two
+// rotary halves; the rotate-half partner b[] is this thread's own second slice) and all of its loads precede its stores - an invariant
+// of this body, kept visible to the compiler by leaving the two pointers possibly-aliasing.
+__global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(const bf16_t* in, int64_t ld_in,
                                                               const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t,
-                                                              const float* __restrict__ sin_t, bf16_t* __restrict__ out,
+                                                              const float* __restrict__ sin_t, bf16_t* out,
                                                               int64_t ld_out, int64_t n_pairs, int H, int B, float eps) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t pair = gid >> 3;  // (row, head)

@@ -50,11 +50,18 @@ class DataType(Enum):
     VIDEO = "video"
 
 
-def tensor_version(t: torch.Tensor) -> int:
-    """In-place version counter of `t` for cache keys. Inference tensors (created under torch.inference_mode(), which the reference's
-    pipeline entry points use: world_generation_pipeline.py:1225) do not track one - reading `_version` raises - and cannot be modified
-    in place outside inference mode either; they get the constant -1 and are identified by storage address + object identity."""
-    return -1 if t.is_inference() else t._version
+def tensor_version(t: torch.Tensor) -> Optional[int]:
+    """In-place version counter of `t` for cache keys - or None: do not cache on this tensor. Inference tensors (created under
+    torch.inference_mode(), which the reference's pipeline entry points use: world_generation_pipeline.py:1225) track no version
+    (reading `_version` raises), yet inside inference mode they CAN be edited in place (crossattn_emb.copy_(new_prompt)): a key of
+    storage address + identity alone would serve stale results, so callers skip their cache for them (a cross-attention K / V rebuild
+    is 28 small GEMMs, a condition re-concatenation ~30 MB - far below 1 % of a forward)."""
+    return None if t.is_inference() else t._version
+
+
+def cacheable(*tensors) -> bool:
+    """True when every tensor has a version counter (see tensor_version)."""
+    return all(not (isinstance(t, torch.Tensor) and t.is_inference()) for t in tensors)
 
 
 def _is_video(data_type) -> bool:
@@ -506,9 +513,10 @@ class VideoExtendGeneralDIT(nn.Module):
         (weight set, context tensor) and reused by the 2 x 35 forwards of a chunk (28 x 2 x 4.3 MB per context). The cache key is
         the context tensor's storage address + in-place version counter + shape / dtype; a new prompt tensor or an in-place edit
         rebuilds the entry."""
+        use_cache = cacheable(crossattn_emb)  # inference tensors: no version counter -> recompute (see tensor_version)
         key = (crossattn_emb.data_ptr(), tensor_version(crossattn_emb), tuple(crossattn_emb.shape), crossattn_emb.dtype, pk["key"])
         cache = self.__dict__.setdefault("_ca_kv_cache", {})
-        hit = cache.get(key)
+        hit = cache.get(key) if use_cache else None
         if hit is not None and hit[0] is crossattn_emb:
             return hit[1]
         B, M = crossattn_emb.shape[:2]
@@ -518,6 +526,8 @@ class VideoExtendGeneralDIT(nn.Module):
         for blk in pk["blocks"]:
             kv = ops.gemm_nt(ctx, blk["ca_kv"])  # [M*B, 2D]
             per_block.append((ops.qk_rmsnorm_rope(kv[:, :D], blk["ca_kn"], None, None, M, B, nH), ops.transpose_v(kv[:, D:], M, B, nH)))
+        if not use_cache:
+            return per_block
         while len(cache) >= 4:  # cond / uncond (+ one spare pair): bounded, oldest first
             cache.pop(next(iter(cache)))
         cache[key] = (crossattn_emb, per_block)  # holding the tensor keeps its storage (hence the address in the key) alive

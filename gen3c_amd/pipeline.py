@@ -224,8 +224,10 @@ class Gen3cPipeline:
             image = load_condition_image(image_path, self.height, self.width)
         else:
             image = image_path
+        # a ready embedding TENSOR has no truth value ("Boolean value of Tensor with more than one value is ambiguous"); "" / None = no negative prompt
+        has_negative = negative_prompt is not None and not (isinstance(negative_prompt, str) and not negative_prompt)
         video = self.generate_from_embeddings(embed(prompt), image, rendered_warp_images, rendered_warp_masks,
-                                              negative_prompt_embedding=embed(negative_prompt) if negative_prompt else None, xt=xt)
+                                              negative_prompt_embedding=embed(negative_prompt) if has_negative else None, xt=xt)
         return video, prompt
 
     @torch.no_grad()

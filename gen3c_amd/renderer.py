@@ -36,9 +36,10 @@ def _p(t: Optional[torch.Tensor], name: str, dtype=f32) -> int:
     return t.data_ptr()
 
 
-def _tensor_version(t: torch.Tensor) -> int:
-    """In-place version counter for cache keys; inference tensors do not track one (and cannot be edited in place outside inference mode)."""
-    return -1 if t.is_inference() else t._version
+def _tensor_version(t: torch.Tensor):
+    """In-place version counter for cache keys, or None = do not memoise on this tensor: inference tensors track no version but can still be
+    edited in place inside torch.inference_mode() (the reference's pipeline entry points run under it, world_generation_pipeline.py:1225)."""
+    return None if t.is_inference() else t._version
 
 
 def _host_inverse(m: torch.Tensor) -> torch.Tensor:
@@ -77,25 +78,35 @@ def reliable_depth_mask_range_batch(depth: torch.Tensor, window_size: int = 5, r
 
 
 _ITEMS_CALL = True   # False: Cache3D.render_cache expands the sources per item and loops forward_warp (the reference's structure; A/B and tests)
-_RENDER_WS: dict = {}
+_RENDER_WS: dict = {}  # insertion-ordered: least recently used first
+_RENDER_WS_MAX_BYTES = int(os.environ.get("G3_RENDER_WS_MAX_BYTES", str(24 << 30)))  # ~1 GB per 32-item workspace at 704 x 1280; of 288 GB
 
 
 def _render_workspace(lib, n: int, h: int, w: int, group_size: int, dev, stream) -> torch.Tensor:
     """Workspace of g3_render_items_f32, cached per (n, h, w, group_size, device, stream) and prepared once (g3_render_workspace_init): the
     kernels keep its accumulator part zero themselves, so a render never clears anything. Launches that share a workspace are ordered on its
-    stream (renders issued from two streams get two workspaces)."""
+    stream (renders issued from two streams get two workspaces). The cache is least-recently-used and bounded by BYTES, not entries: one
+    two-stream render already holds four shapes (chunk and tail halves on two streams), a second resolution or an uneven multi-GPU shard
+    must not push those out and re-run the init (a memset of the accumulator) on every call."""
     key = (n, h, w, group_size, str(dev), int(stream or 0))
-    t = _RENDER_WS.get(key)
+    t = _RENDER_WS.pop(key, None)
     if t is None:
         nbytes = int(lib.g3_render_workspace_bytes(n, h, w, group_size))
+        held = sum(v.numel() for v in _RENDER_WS.values())
+        while _RENDER_WS and held + nbytes > _RENDER_WS_MAX_BYTES:
+            held -= _RENDER_WS.pop(next(iter(_RENDER_WS))).numel()
         t = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         off = (-t.data_ptr()) % 256
         t = t[off:off + nbytes]
         _lib.check(lib.g3_render_workspace_init(t.data_ptr(), n, h, w, group_size, stream), "g3_render_workspace_init")
-        while len(_RENDER_WS) >= 4:  # chunk size + a ragged tail per resolution (and stream): bounded
-            _RENDER_WS.pop(next(iter(_RENDER_WS)))
-        _RENDER_WS[key] = t
+    _RENDER_WS[key] = t  # (re-)inserted at the most-recently-used end
     return t
+
+
+def _drop_render_workspace(t: torch.Tensor):
+    """A failed g3_render_items_f32 may leave its workspace's accumulator / tmin planes non-clean: never reuse it."""
+    for k in [k for k, v in _RENDER_WS.items() if v is t]:
+        del _RENDER_WS[k]
 
 
 _TWO_STREAM_CHUNKS = os.environ.get("G3_RENDER_TWO_STREAMS", "1") != "0"
@@ -279,6 +290,8 @@ class Cache3D_Base:
             memo.clear()
 
         def memoised(key, refs, make):
+            if any(r.is_inference() for r in refs):  # no version counter: an in-place edit would go unnoticed -> recompute
+                return make()
             hit = memo.get(key)
             if hit is None or any(a is not b for a, b in zip(hit[0], refs)):
                 hit = memo[key] = (refs, make())  # `refs` keeps the keyed tensors alive, so an id() cannot be recycled under the entry
@@ -313,11 +326,13 @@ class Cache3D_Base:
 
         def launch(i, j, st):
             ws = _render_workspace(lib, j - i, H, W, 2, dev, st)
-            _lib.check(lib.g3_render_items_f32(_p(pts_src, "points_src"), _p(img_src, "image_src"), _p(msk_src, "mask_src"), _p(bnd_src, "boundary_src", torch.uint8),
+            rc = lib.g3_render_items_f32(_p(pts_src, "points_src"), _p(img_src, "image_src"), _p(msk_src, "mask_src"), _p(bnd_src, "boundary_src", torch.uint8),
                                                _p(src_index[i:j], "src_index", torch.int32), _p(w2cs[i:j], "w2c"), _p(Ks[i:j], "K"),
                                                _p(kinv[i:j], "Kinv") if kinv is not None else 0, ws.data_ptr(), _p(frames[i:j], "frame"),
-                                               _p(masks[i:j], "mask"), _p(depths[i:j], "depth") if depths is not None else 0, 0, j - i, n_src, H, W, 2, st),
-                       "g3_render_items_f32")
+                                               _p(masks[i:j], "mask"), _p(depths[i:j], "depth") if depths is not None else 0, 0, j - i, n_src, H, W, 2, st)
+            if rc != 0:
+                _drop_render_workspace(ws)
+            _lib.check(rc, "g3_render_items_f32")
 
         chunks = [(i, min(i + step, m)) for i in range(0, m, step)]
         if _TWO_STREAM_CHUNKS and dev.type == "cuda":

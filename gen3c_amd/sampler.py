@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dit import DataType, tensor_version
+from .dit import DataType, cacheable, tensor_version
 from .parallel import cat_outputs_cp, split_inputs_cp
 
 
@@ -204,7 +204,10 @@ class Gen3CDenoiser:
                 return (id(v), v.data_ptr(), tensor_version(v)) if isinstance(v, torch.Tensor) else (id(v),)
             key = (B,) + tuple(_ident(v) for v in condition.to_dict().values()) + tuple(_ident(v) for v in uncondition.to_dict().values())
             fc = self._fused_cache
-            if fc is None or fc[0] != key:
+            if not cacheable(*condition.to_dict().values(), *uncondition.to_dict().values()):
+                # inference tensors carry no version counter: an in-place edit would go unnoticed -> rebuild the batched arguments every step
+                fc = (key, self._fused_cond_uncond_kwargs(condition, uncondition, B))
+            elif fc is None or fc[0] != key:
                 # (the cache entry keeps the condition objects alive, so the ids in the key cannot be recycled while it is valid)
                 fc = self._fused_cache = (key, self._fused_cond_uncond_kwargs(condition, uncondition, B), condition.to_dict(), uncondition.to_dict())
             fused = fc[1]

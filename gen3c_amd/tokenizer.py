@@ -214,14 +214,17 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         _lib.check(_lib.load().g3_resample_cl_bf16(_ptr(x), _ptr(out), T, H, W, C, mode, _st()), "g3_resample_cl_bf16")
         return out
 
-    def _res_block(self, x: torch.Tensor, name: str) -> torch.Tensor:
+    def _res_block(self, x: torch.Tensor, name: str, next_is_norm: bool = True) -> torch.Tensor:
+        """next_is_norm: the block's output feeds a CausalNormalize (the next res block's norm1, an attention norm, norm_out) - its GroupNorm
+        statistics are then produced by the last convolution's epilogue. False for the two blocks in front of a re-sampling stage
+        (encoder.down.0.block.1 -> downsample, decoder.up.1.block.2 -> upsample): nobody would read them."""
         h = self._gn(x, f"{name}.norm1", True)
         h = self._conv(h, f"{name}.conv1.0", "s3")
         h = self._conv(h, f"{name}.conv1.1", "t3", stats=True)
         h = self._gn(h, f"{name}.norm2", True)
         h = self._conv(h, f"{name}.conv2.0", "s3")
         skip = self._conv(x, f"{name}.nin_shortcut", "p1") if f"{name}.nin_shortcut.conv3d.weight" in self._w else x
-        return self._conv(h, f"{name}.conv2.1", "t3", residual=skip, stats=True)  # next: a res block's norm1 / an attention norm / norm_out
+        return self._conv(h, f"{name}.conv2.1", "t3", residual=skip, stats=next_is_norm)
 
     def _spatial_attn(self, x: torch.Tensor, name: str) -> torch.Tensor:
         T, H, W, C = x.shape
@@ -289,7 +292,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         h = self._conv(h, "encoder.conv_in.1", "t3", stats=True)
         for lvl in range(3):
             for j in range(self.num_res_blocks):
-                h = self._res_block(h, f"encoder.down.{lvl}.block.{j}")
+                h = self._res_block(h, f"encoder.down.{lvl}.block.{j}", next_is_norm=not (lvl == 0 and j == self.num_res_blocks - 1))
             if lvl == 0:
                 d = "encoder.down.0.downsample"
                 h = self._conv(h, f"{d}.conv1", "s3s2", residual=self._resample(h, 0))
@@ -321,7 +324,7 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         h = self._res_block(h, "decoder.mid.block_2")
         for lvl in (2, 1, 0):
             for j in range(self.num_res_blocks + 1):
-                h = self._res_block(h, f"decoder.up.{lvl}.block.{j}")
+                h = self._res_block(h, f"decoder.up.{lvl}.block.{j}", next_is_norm=not (lvl == 1 and j == self.num_res_blocks))
             if lvl == 1:
                 u = "decoder.up.1.upsample"
                 hu = self._resample(h, 2)

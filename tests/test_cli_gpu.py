@@ -173,6 +173,54 @@ def test_persistent_model_seed_and_two_requests(tmp_path):
     assert np.load(r["video_save_path"])["video"].shape == (9, H, 2 * W, 3)
 
 
+def test_serving_boundary_over_the_resident_model(tmp_path):
+    """SURVEY.md 8-f4 / VERDICT r3 #8: the call sequence the reference's server makes (server.py:123-236 -> server_cosmos_base.py:46-214) -
+    seed_model(SeedingRequest) -> request_inference(InferenceRequest) -> inference_result_or_none - through gen3c_amd.serving.Gen3cInferenceModel
+    on the REAL resident model (HIP kernels, tiny widths): record fields, shapes and the one-frame overlap of consecutive requests."""
+    import asyncio
+    from gen3c_amd import api_types as api
+    from gen3c_amd import gen3c_persistent as gp
+    from gen3c_amd.serving import Gen3cInferenceModel
+    H, W = 64, 96
+    args = gp.create_parser().parse_args(["--height", str(H), "--width", str(W), "--num_steps", "2", "--random_init", "--tiny",
+                                          "--video_save_folder", str(tmp_path / "out"), "--video_save_name", "srv"])
+    resident = gp.Gen3cPersistentModel(args)
+    n = resident.frames_per_batch
+    imgs, depth, mask, K, w2c = _scene(H, W, 1, seed=4)
+    c2w = np.linalg.inv(w2c)[:, :3].astype(np.float32)
+    fl = np.stack([K[:, 0, 0], K[:, 1, 1]], 1).astype(np.float32)
+    pp = np.stack([K[:, 0, 2] / W, K[:, 1, 2] / H], 1).astype(np.float32)
+
+    def cams(x0):
+        c = np.repeat(np.eye(4, dtype=np.float32)[None, :3], n, 0)
+        c[:, 0, 3] = x0 + 0.003 * np.arange(n)
+        return c
+
+    async def drive():
+        model = Gen3cInferenceModel(resident, compress_inference_results=False)
+        with pytest.raises(ValueError, match="not seeded"):
+            model.request_inference(api.InferenceRequest(request_id="early", timestamps=np.zeros(n, np.float32), cameras_to_world=cams(0), focal_lengths=np.repeat(fl, n, 0),
+                                                         principal_points=np.repeat(pp, n, 0), resolutions=np.tile([[W, H]], (n, 1))))
+        seeded = await model.seed_model(api.SeedingRequest(request_id="seed", images=((imgs + 1) / 2).transpose(0, 2, 3, 1).astype(np.float32), depths=depth[:, 0],
+                                                           cameras_to_world=c2w, focal_lengths=fl, principal_points=pp))
+        results = []
+        for i, x0 in enumerate((0.0, 0.003 * (n - 1))):
+            req = api.InferenceRequest(request_id=f"req{i}", timestamps=np.zeros(n, np.float32), cameras_to_world=cams(x0), focal_lengths=np.repeat(fl, n, 0),
+                                       principal_points=np.repeat(pp, n, 0), resolutions=np.tile([[2 * W, 2 * H]], (n, 1)), framerate=24.0, return_depths=(i == 0))
+            task = model.request_inference(req)
+            await task
+            results.append(model.inference_result_or_none(req.request_id))
+        return model, seeded, results
+
+    model, seeded, (r0, r1) = asyncio.run(drive())
+    assert isinstance(seeded, api.SeedingResult) and seeded.depths is None and seeded.resolutions.tolist() == [[W, H]]  # the request brought its depths
+    assert isinstance(r0, api.InferenceResult) and r0.images.shape == (n, H, W, 3) and r0.depths.shape == (n, H, W) and len(r0.result_ids) == n
+    assert r0.request_id == "req0" and r0.runtime_ms > 0 and np.isfinite(r0.depths[-1]).all()
+    assert r1.images.shape == (n - 1, H, W, 3) and r1.depths is None and r1.cameras_to_world.shape == (n - 1, 3, 4)  # one overlap frame regenerated, not returned
+    assert len(model.pose_history_w2c) == 2 and np.array_equal(model.pose_history_w2c[1][0], model.pose_history_w2c[0][-1])
+    assert model.metadata()["inference_resolution"] == [(W, H)] and model.min_frames_per_request() == n
+
+
 def test_cli_loads_checkpoint_layout(tmp_path):
     """The checkpoint path of the entry points (world_generation_pipeline.py:182-186, inference_utils.py:240-242,327-347):
     checkpoints/Gen3C-Cosmos-7B/model.pt with `net.*` keys (+ TE `_extra_state` blobs and `logvar.*` that must be ignored) and

@@ -52,11 +52,12 @@ def test_fused_cond_uncond_arguments():
 def test_cache_keys_work_on_inference_tensors():
     """the reference wraps its pipeline entry points in torch.inference_mode() (world_generation_pipeline.py:1225); inference
     tensors raise on `_version`. The cache keys must not."""
-    from gen3c_amd.dit import VideoExtendGeneralDIT, tensor_version
+    from gen3c_amd.dit import VideoExtendGeneralDIT, cacheable, tensor_version
     with torch.inference_mode():
         t = torch.zeros(3)
-    assert t.is_inference() and tensor_version(t) == -1
+    assert t.is_inference() and tensor_version(t) is None  # = do not cache on this tensor (VERDICT r3 #9)
     u = torch.zeros(3)
+    assert cacheable(u, None, 3.0) and not cacheable(u, t)
     v0 = tensor_version(u)
     u.add_(1)
     assert tensor_version(u) == v0 + 1

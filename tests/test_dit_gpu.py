@@ -171,6 +171,13 @@ def test_dit_forward_under_inference_mode_matches_no_grad():
             y1 = net(x=x, **kw)
             y2 = net(x=x, **kw)  # second call: cached cross-attention K / V, cached tables
             assert torch.equal(y1, y2)
+            # an IN-PLACE edit of the context between two forwards must be seen. Ordinary tensors carry a version counter (part of
+            # the cross-attention K / V cache key); inference tensors do not - the cache is skipped for them instead of trusting address + identity.
+            ctx.mul_(-0.5)
+            y3 = net(x=x, **kw)
+            assert not torch.equal(y3, y1), "stale cross-attention K / V after an in-place edit of crossattn_emb"
+            ctx.mul_(-2.0)  # exact in bf16: back to the original context
+            assert torch.equal(net(x=x, **kw), y1)
             return y1.float().cpu()
 
     assert torch.equal(run(torch.inference_mode), run(torch.no_grad))

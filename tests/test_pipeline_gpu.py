@@ -79,6 +79,12 @@ def _chain(n_buffers: int, guidance: float, num_steps: int):
         out2 = pipe.generate(prompt="a prompt", image_path=image, negative_prompt="a negative prompt", rendered_warp_images=renders,
                              rendered_warp_masks=masks, xt=xt.to(dev))
         assert isinstance(out2, tuple) and out2[1] == "a prompt" and np.array_equal(out2[0], video)
+        # ready embedding TENSORS for both prompts (a tensor has no truth value); "" means no negative prompt
+        out3 = pipe.generate(prompt=prompt, image_path=image, negative_prompt=negp, rendered_warp_images=renders, rendered_warp_masks=masks, xt=xt.to(dev))
+        assert np.array_equal(out3[0], video)
+        out4 = pipe.generate(prompt=prompt, image_path=image, negative_prompt="", rendered_warp_images=renders, rendered_warp_masks=masks, xt=xt.to(dev))
+        out5 = pipe.generate(prompt=prompt, image_path=image, negative_prompt=None, rendered_warp_images=renders, rendered_warp_masks=masks, xt=xt.to(dev))
+        assert np.array_equal(out4[0], out5[0])
 
     # ---- the same chain from the CPU oracles (fp32)
     src = []
