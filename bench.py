@@ -272,20 +272,36 @@ def autotune_cp(net, den, xt, cond, uncond, dev, dist, rank: int = 0, progress: 
             if progress is not None:
                 progress.update(candidate=cand, table=table, failed=failed)
             ms, err = [0.0, 0.0], None
+
+            def all_ok() -> bool:
+                """Barrier + agreement in one collective: every rank reports whether it can still run this candidate. Keeps the collective
+                sequence identical on all ranks when ONE of them raised outside a step (a rank that skipped a barrier the others enter would
+                hang them); a raise in the middle of a step's exchanges cannot be repaired - RunGuard ends the run with a line then."""
+                f = torch.tensor([0.0 if err is None else 1.0], device=dev, dtype=torch.float64)
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                return float(f.item()) == 0.0
+
             try:
                 if _injected("autotune", rank, cand):
                     raise RuntimeError(f"injected failure in candidate {cand} on rank {rank}")
                 cpa.configure(head_groups=G, kernel=kern, schedule=sched)
-                ms = []
-                for rep in range(2):
-                    dist.barrier()
+            except Exception as e:  # this rank cannot even set the candidate up
+                err = repr(e)
+            times = []
+            for rep in range(2):
+                if not all_ok():
+                    err = err or "failed on another rank"
+                    break
+                try:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     den.denoise_step(xt, 0, cond, uncond, 1.0, 0.001, 1)
                     torch.cuda.synchronize()
-                    ms.append((time.perf_counter() - t0) * 1e3)
-            except Exception as e:  # this rank cannot run the candidate: tell the others through the agreement below
-                err = repr(e)
+                    times.append((time.perf_counter() - t0) * 1e3)
+                except Exception as e:  # (if every rank raises at the same point the sequence stays aligned; otherwise see all_ok)
+                    err = repr(e)
+            if err is None:
+                ms = times
             t = torch.tensor([ms[1] if err is None else 0.0, 0.0 if err is None else 1.0], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # [slowest rank's time, 1 if any rank failed]
             eff = getattr(cpa, "effective", None) or {}

@@ -29,12 +29,12 @@ def karras_sigmas(num_steps: int) -> torch.Tensor:
 def denoise_step(net_fn, xt, step_index, gt_latent, indicator, pose, num_steps, guidance, augment_sigma, seed):
     """One iteration of the loop at model_v2w.py:130-149. net_fn(x, timesteps, pose) -> network output;
     the unconditional branch gets pose = zeros (model_gen3c.py:126-127)."""
-    sig = karras_sigmas(num_steps)
+    sig = karras_sigmas(num_steps).to(gt_latent.device)  # (device-agnostic: the full-size chains of tools/psnr_vs_oracle.py run on the GPU's torch)
     sigma, sigma_next = sig[step_index], sig[step_index + 1]
     ind = indicator.clone()
     if augment_sigma >= float(sigma):
         ind = torch.zeros_like(ind)
-    noise = torch.from_numpy(np.random.RandomState(seed).standard_normal(tuple(gt_latent.shape)).astype(np.float32))
+    noise = torch.from_numpy(np.random.RandomState(seed).standard_normal(tuple(gt_latent.shape)).astype(np.float32)).to(gt_latent.device)
     aug = gt_latent + noise * augment_sigma
     aug = aug * (1 / (augment_sigma ** 2 + SIGMA_DATA ** 2) ** 0.5)        # scheduler.precondition_inputs
     aug = aug / (1 / (sigma ** 2 + SIGMA_DATA ** 2) ** 0.5)               # _reverse_precondition_input

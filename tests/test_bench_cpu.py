@@ -104,7 +104,7 @@ def test_cp_autotune_picks_the_fastest_candidate_and_reports(monkeypatch):
     best, table, failed = bench.autotune_cp(net, FakeDen(), None, None, None, torch.device("cpu"), FakeDist)
     assert failed == [] and len(table) == 16 and {r["schedule"] for r in table} == {"gather_first", "local_first"} and {r["head_groups"] for r in table} == {1, 2, 4, 8}
     assert (best["head_groups"], best["kernel"], best["schedule"]) == (2, "w4b", "local_first")
-    assert net._cp_attn.cfg == (2, "w4b", "local_first") and net._tune_blocks is None and FakeDist.reduced == 16
+    assert net._cp_attn.cfg == (2, "w4b", "local_first") and net._tune_blocks is None and FakeDist.reduced == 16 * 3  # per candidate: 2 barrier-agreements + the result
 
     class T:
         def __init__(self, ms):

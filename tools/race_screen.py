@@ -135,6 +135,33 @@ for (Sq, Skv, H, variant) in [(7040, 14080, 4, 11), (7040, 14080, 4, 4), (1000, 
         return torch.cat([op.reshape(-1), lse.reshape(-1)])
     a, b = both(run)
     report(f"split-KV partial attention Sq={Sq} Skv={Skv} H={H} variant={variant}", a, b)
+# ---- the whole tokenizer at the size bench.py times it (round 4): 121 x 704 x 1280, channels = 128 - the 1.79 GB activations, the spatial attention's frames
+# on two streams with per-stream score buffers, GroupNorm statistics from conv epilogues, all 16 latent frames in the temporal attention
+if "--no-tokenizer" not in sys.argv:
+    import bench  # noqa: E402
+    from gen3c_amd.tokenizer import CausalVideoTokenizerNet  # noqa: E402
+    for lib in (base, alt):
+        lib.g3_set_option(b"attn_variant", 0)
+        lib.g3_set_option(b"gemm_pingpong", 3)
+        lib.g3_set_option(b"gemm_persistent", 0)
+        lib.g3_set_option(b"conv_w4", 1)
+    tnet = CausalVideoTokenizerNet(channels=128, device=dev)
+    tnet.init_random(seed=3)
+    clip = bench.tokenizer_bench_clip(dev)
+    outs = []
+    for lib in (base, alt, base):
+        _lib._lib = lib  # the product's loader hands out this handle
+        z = tnet.encoder(clip)
+        y = tnet.decoder(z)
+        torch.cuda.synchronize()
+        outs.append((z, y))
+    _lib._lib = base
+    # the fp64 atomics that collect GroupNorm statistics may add in any order: bitwise equality is expected in practice (measured), a last-bit
+    # difference of a statistic would show as ~1e-7, a race as >= 1e-3
+    for what, i in (("encode", 0), ("decode", 1)):
+        report(f"tokenizer {what} 121x704x1280 channels=128, product vs jitter build", outs[0][i], outs[1][i])
+        report(f"tokenizer {what} 121x704x1280 channels=128, product run twice", outs[0][i], outs[2][i])
+    del outs, clip, tnet
 for lib in (base, alt):
     lib.g3_set_option(b"attn_variant", 0)
     lib.g3_set_option(b"gemm_pingpong", 3)
