@@ -92,6 +92,65 @@ def cpu_baseline(threads: int, blocks: int = 1):
                        f"per-block linearity of the extrapolation checked once: profiles/r3_cpu_baseline_linearity.txt")
 
 
+def cpu_baseline_render(threads: int):
+    """Renderer leg of the CPU baseline: oracle/warp_oracle.py ("port": numpy restatement of the reference's forward_warp, pinned bit-exact to it on
+    flow / masks) on the host, ONE reference pair (2 items) of bench.py's 704 x 1280 scene, without and with foreground masking (the mesh
+    occlusion through oracle/c/ray_tri.c, OpenMP over the rays). The reference's own forward_warp timed on CPU tensors: profiles/r4_cpu_reference.json."""
+    from oracle import warp_oracle
+    h, w = 704, 1280
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    depth = 4.0 + 0.0004 * xs + 0.0002 * ys
+    for (cy, cx, r, zz) in ((h * 0.4, w * 0.3, h * 0.22, 1.6), (h * 0.65, w * 0.7, h * 0.18, 2.4)):
+        depth = np.where((ys - cy) ** 2 + (xs - cx) ** 2 < r * r, zz + 0.0001 * xs, depth)
+    depth = depth.astype(np.float32)
+    img = np.stack([np.sin(xs * 0.021 + c) * np.cos(ys * 0.017 - c) for c in range(3)], 0).astype(np.float32)
+    K = np.array([[1000.0, 0, w / 2], [0, 1000.0, h / 2], [0, 0, 1]], np.float32)
+    pts = warp_oracle.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    rel = warp_oracle.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    bnd = ~warp_oracle.reliable_depth_mask(depth[None, None])
+    w2c = np.stack([np.eye(4, dtype=np.float32)] * 2)
+    w2c[:, 0, 3] = (0.1, 0.11)
+    out = {}
+    for fg in (False, True):
+        t0 = time.perf_counter()
+        warp_oracle.forward_warp(np.stack([img] * 2), np.concatenate([rel] * 2), np.concatenate([pts] * 2), w2c, np.stack([K] * 2),
+                                 foreground_masking=fg, boundary_mask=np.concatenate([bnd[:, 0]] * 2) if fg else None,
+                                 ray_triangle_fn=warp_oracle.ray_triangle_depth_c if fg else None)
+        dt = time.perf_counter() - t0
+        out["foreground_masking" if fg else "plain"] = dict(value=round(43.2e6 * 2 / dt / 1e9, 4), unit="GB/s", ms_per_item=round(dt / 2 * 1e3, 1), seconds=round(dt, 2))
+    out.update(cores=threads, kind="port", sample="oracle/warp_oracle.py (numpy; ray x triangle in C), one pair of 704x1280 items of the bench scene, 43.2 MB algorithmic per item")
+    return out
+
+
+def cpu_baseline_tokenizer(threads: int):
+    """Tokenizer leg: oracle/tokenizer_oracle.py ("port", fp32 torch on the host) encode + decode of a 9 x 352 x 640 clip at channels = 128 - 1/32 of
+    the benchmark clip's latent volume (2 of 16 latent frames x 1/4 of the pixels; the attention share shrinks with the pixel count, so the
+    extrapolation by latent volume flatters the CPU slightly). The reference's own modules on CPU: profiles/r4_cpu_reference.json."""
+    from oracle import tokenizer_oracle as tok
+    from gen3c_amd.tokenizer import CausalVideoTokenizerNet
+    torch.set_num_threads(threads)
+    keys = CausalVideoTokenizerNet(channels=128, device="cpu").expected_keys()
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shape in keys.items():
+        sd[k] = (torch.rand(shape, generator=g) + 0.5) if k.endswith("norm.weight") else (torch.randn(shape, generator=g) * (0.05 if k.endswith(".bias") else (1.0 / max(1, int(np.prod(shape[1:])))) ** 0.5))
+    T, H, W = 9, 352, 640
+    x = torch.rand(1, 3, T, H, W, generator=g) * 2 - 1
+    frac = (1 + (T - 1) / 8) * H * W / (16 * 704 * 1280)
+    out = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        z = tok.encoder(sd, x)
+        te = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tok.decoder(sd, z)
+        td = time.perf_counter() - t0
+    for name, dt, tflop in (("encode", te, 35.7), ("decode", td, 61.3)):
+        out[name] = dict(value=round(tflop * frac / dt, 4), unit="TFLOP/s", seconds=round(dt, 2), full_clip_seconds_extrapolated=round(dt / frac, 1))
+    out.update(cores=threads, kind="port", sample=f"oracle/tokenizer_oracle.py fp32, channels=128, one {T}x{H}x{W} clip = {frac:.4f} of the 121x704x1280 clip's work")
+    return out
+
+
 TOK_FIXTURE = ROOT / "tests" / "golden" / "tokenizer_fullsize_samples.npz"
 
 
@@ -628,7 +687,14 @@ def main():
                 out["roofline_extras_error"] = repr(e)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(threads=min(32, os.cpu_count() or 1))  # 32 threads measured fastest on the 2x64-core EPYC host
+                nthr = min(32, os.cpu_count() or 1)  # 32 threads measured fastest on the 2x64-core EPYC host
+                out["cpu_baseline"] = cpu_baseline(threads=nthr)
+                for leg, fn in (("render", cpu_baseline_render), ("tokenizer", cpu_baseline_tokenizer)):  # the chunk's other two stages
+                    try:
+                        out["cpu_baseline"][leg] = fn(nthr)
+                    except Exception as e:
+                        out["cpu_baseline"][leg] = {"error": repr(e)}
+                out["cpu_baseline"]["reference_on_cpu"] = "the reference's own DiT / forward_warp / tokenizer timed on CPU in the build container: profiles/r4_cpu_reference.json"
             except Exception as e:  # the baseline must never hide the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

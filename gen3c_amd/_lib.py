@@ -69,6 +69,7 @@ SIGNATURES = {
     "g3_softmax_rows_bf16": [vp, i64, i32, i32, f32, vp],
     "g3_transpose2d_bf16": [vp, i64, vp, i64, i32, i32, vp],
     "g3_temporal_attn_cl_bf16": [vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "g3_spatial_attn_d512_bf16": [vp, vp, vp, i64, i64, vp, i32, i32, f32, vp],
     "g3_edm_prepare_input_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, vp],
     "g3_edm_cfg_euler_step_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp],
 }

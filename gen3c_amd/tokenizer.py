@@ -23,6 +23,8 @@ bf16 = torch.bfloat16
 # 0: GroupNorm statistics always by their own pass over the tensor (A/B switch; default: produced in the epilogue of the convolution that writes it)
 _FUSE_GN_STATS = os.environ.get("G3_FUSE_GN_STATS", "1") != "0"
 # streams the spatial attention's frames are spread over (1 = all on the caller's stream)
+# 0: the spatial attention as three kernels per frame (scores GEMM -> row softmax -> P.V GEMM; rounds 1-3, kept for A/B and for widths other than 512)
+_FLASH_SPATIAL_ATTN = os.environ.get("G3_TOK_FLASH_ATTN", "1") != "0"
 _ATTN_STREAMS = max(1, int(os.environ.get("G3_TOK_ATTN_STREAMS", "2")))  # measured 1: 47.0 / 73.0 ms, 2: 45.0 / 70.4, 3: 45.0 / 70.7, 4: 45.4 / 71.3, 6: 45.8 / 71.1 (encode / decode, one run)
 
 
@@ -234,8 +236,16 @@ class CausalVideoTokenizerNet(torch.nn.Module):
         k = self._conv(hn, f"{name}.k", "p1").view(T, HW, C)
         v = self._conv(hn, f"{name}.v", "p1").view(T, HW, C)
         o = torch.empty((T, HW, C), dtype=bf16, device=x.device)
-        ldp = ops.ceil_to(HW, 8)
         lib = _lib.load()
+        if _FLASH_SPATIAL_ATTN and C == 512 and HW % 64 == 0 and x.is_cuda:
+            # One flash-style pass per frame (csrc/attention_d512.hip): no 14 080 x 14 080 score matrix in HBM, no separate softmax launch. V^T of
+            # ALL frames by one transpose of the [T HW, C] matrix: frame f's V^T = columns [f HW, (f + 1) HW) of the [C, T HW] result.
+            vT = torch.empty((C, T * HW), dtype=bf16, device=x.device)
+            _lib.check(lib.g3_transpose2d_bf16(_ptr(v), C, _ptr(vT), T * HW, T * HW, C, _st()), "g3_transpose2d_bf16")
+            _lib.check(lib.g3_spatial_attn_d512_bf16(_ptr(q), _ptr(k), _ptr(vT), T * HW, HW, _ptr(o), T, HW, float(C) ** -0.5, _st()),
+                       "g3_spatial_attn_d512_bf16")
+            return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
+        ldp = ops.ceil_to(HW, 8)
         # Frames are independent (time2batch, layers3d.py:362-364). One frame's products do not fill the chip - scores = q k^T is 8 K tiles per
         # 256 x 256 output tile (its launches wait on their stores), p v has (HW / 256) x 2 = 110 tiles for 256 CUs at 704 x 1280 - so the
         # frames go round-robin over a few streams, each with its own score / V^T buffers: the tiles of one frame's launch fill the CUs another

@@ -277,6 +277,12 @@ int g3_softmax_rows_bf16(void* x, int64_t ld, int rows, int n, float scale, void
 int g3_transpose2d_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int R, int C, void* stream);
 int g3_temporal_attn_cl_bf16(const void* q, const void* k, const void* v, void* o, int T, int HW, int C, float scale,
                              void* stream);
+/* CausalAttnBlock's attention core (tokenizer/modules/layers3d.py:362-377: per frame w = softmax(q^T k * C^-0.5), h = v w^T) for C = 512 in ONE
+ * flash-style pass: q, k, o [frames][hw][512] bf16 (channels-last pixels), vt = V^T [frames][512][ld_vt] (g3_transpose2d_bf16 per frame;
+ * vt_frame_stride in elements), hw % 64 == 0. fp32 softmax statistics and accumulation, P rounded to bf16 before P.V like the bf16 reference.
+ * Replaces the scores-GEMM + g3_softmax_rows_bf16 + P.V-GEMM sequence of earlier rounds (csrc/attention_d512.hip). */
+int g3_spatial_attn_d512_bf16(const void* q, const void* k, const void* vt, int64_t ld_vt, int64_t vt_frame_stride, void* o, int frames,
+                              int hw, float softmax_scale, void* stream);
 
 #ifdef __cplusplus
 }

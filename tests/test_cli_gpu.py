@@ -246,6 +246,16 @@ def test_cli_loads_checkpoint_layout(tmp_path):
     _script_archive({k: v.float().cpu() for k, v in tsd.items() if k.startswith(("encoder.", "quant_conv."))}, tdir / "encoder.jit")
     _script_archive({k: v.float().cpu() for k, v in tsd.items() if k.startswith(("post_quant_conv.", "decoder."))}, tdir / "decoder.jit")
     torch.save((torch.zeros(16 * 32), torch.ones(16 * 32)), tdir / "mean_std.pt")
+    # the checkpoint PSNR harness on this very layout - HIP vs the oracle chain in the reference's precision (bf16) vs fp32, per frame,
+    # non-zero exit if a HIP frame is more than 0.1 dB worse than the reference-precision frame
+    import json
+    from tools import psnr_vs_oracle
+    rc = psnr_vs_oracle.main(["--checkpoint_dir", str(tmp_path / "ckpt"), "--tiny", "--height", str(H), "--width", str(W), "--num_steps", "3",
+                              "--video_save_folder", str(tmp_path / "out"), "--json", str(tmp_path / "psnr.json")])
+    rep = json.loads((tmp_path / "psnr.json").read_text())
+    print(f"[psnr harness, tiny checkpoint] hip vs fp32 {min(rep['psnr_hip_vs_fp32']):.2f}..{max(rep['psnr_hip_vs_fp32']):.2f} dB, reference precision vs fp32 "
+          f"{min(rep['psnr_ref_vs_fp32']):.2f}..{max(rep['psnr_ref_vs_fp32']):.2f} dB, worst delta {rep['worst_delta_db']:+.2f} dB")
+    assert rc == 0 and rep["passed"] and rep["frames"] == 9 and len(rep["psnr_hip_vs_fp32"]) == 9
     ys, xs = np.mgrid[0:H, 0:W]
     Image.fromarray(np.stack([(xs * 2) % 256, (ys * 3) % 256, ((xs + ys) * 2) % 256], -1).astype(np.uint8)).save(tmp_path / "in.png")
     np.savez(tmp_path / "depth.npz", depth=(2.0 + 0.01 * xs).astype(np.float32))

@@ -100,3 +100,37 @@ def test_full_size_block_hip_vs_reference_precision_oracle():
     print(f"[dit D=4096 H=32, 1 block, 56320 tokens] vs the fp32 oracle: HIP {r_hip:.3e} | the oracle in bf16 (reference rounding points, torch kernels of this device) {r_ref:.3e}"
           f" | HIP vs bf16 oracle {_rel(y, y16):.3e}")
     assert r_hip <= SLACK * r_ref
+
+
+def test_fp8_qk_emulation_study():
+    """VERDICT r3 #10 (north_star names "MFMA bf16/fp8 QK^T"): can an e4m3 QK^T hold the attention tolerance (rel-L2 <= 1e-2 vs fp32)? Decided BEFORE writing a
+    kernel, by emulating exactly what v_mfma_f32_32x32x64_f8f6f4 would compute: Q and K quantised to OCP e4m3 with one scale per (head, tensor) (amax -> 448),
+    products exact, fp32 accumulation; softmax in fp32, P and V in bf16 as today. Expectation from the format: 3 mantissa bits = 2^-4 relative rounding per
+    element -> logit noise ~0.044 -> P perturbed by ~4 % per key, which zero-mean V does not average away. Measured and recorded (profiles/r4_parity_measured.txt);
+    the assertion documents the outcome: fp8 QK^T is >= 3x outside the tolerance the bf16 kernels meet with margin, so no fp8 kernel is shipped."""
+    from oracle import dit_oracle
+    dev = torch.device("cuda:0")
+    HD = 128
+    if not hasattr(torch, "float8_e4m3fn"):
+        pytest.skip("torch build without float8_e4m3fn")
+    out = {}
+    for S, H in ((8192, 4), (56320, 1)):
+        g = torch.Generator(device=dev).manual_seed(41 + S)
+        q, k, v = (torch.randn(S, 1, H, HD, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+        rows = torch.randint(0, S, (512,), device=dev, generator=g)
+
+        def quant(t):  # per (head, tensor) scale, as a kernel would apply on the way into LDS
+            amax = t.float().abs().amax(dim=(0, 1, 3), keepdim=True)
+            sc = 448.0 / amax
+            return (t.float() * sc).to(torch.float8_e4m3fn).float() / sc
+
+        def attn(qq, kk):
+            sc = torch.einsum("sbhd,tbhd->bhst", qq[rows].float(), kk.float()) / math.sqrt(HD)
+            p = torch.softmax(sc, dim=-1)
+            return torch.einsum("bhst,tbhd->sbhd", p.to(torch.bfloat16).float(), v.float())
+
+        ref = attn(q, k)
+        out[S] = (_rel(attn(quant(q), quant(k)), ref), _rel(attn(quant(q), k), ref))
+        print(f"[fp8 QK^T emulation, S={S}, N(0,1) operands, {rows.numel()} sampled rows] rel-L2 vs fp32 attention: e4m3 Q and K {out[S][0]:.3e} | e4m3 Q only {out[S][1]:.3e} "
+              f"(bf16 kernels: ~3e-3; tolerance 1e-2)")
+    assert out[56320][0] > 1e-2, "e4m3 QK^T met the attention tolerance on this data - revisit the decision not to build it"

@@ -9,7 +9,7 @@ profiles/r4_cpu_reference.json. Three stages, each on a stated, bounded sample:
              Third-party arithmetic behind the shims: TE RMSNorm / DotProductAttention -> torch (F.scaled_dot_product_attention).
   render     forward_warp_utils_pytorch.forward_warp (:171-336) on CPU tensors, 704 x 1280, pairs of items as Cache3D_Base.render_cache calls it
              (cache_3d.py:163-214), without foreground masking; with foreground masking the reference needs NVIDIA Warp on a CUDA device
-             (ray_triangle_intersection_warp.py) - its hook is pointed at the oracle's C restatement (oracle/c/ray_tri.c, 8 OpenMP-less threads: 1)
+             (ray_triangle_intersection_warp.py) - its hook is pointed at the oracle's C restatement (oracle/c/ray_tri.c, OpenMP over the rays)
              and that leg is labelled "reference + port".
   tokenizer  TokenizerModels.CV (CV8x8x8_720p, channels = 128: EncoderFactorized / DecoderFactorized, layers3d.py:669-949) encoder_jit /
              decoder_jit on one clip (`--clip T,H,W`, default the full 121 x 704 x 1280), fp32 and bf16.
@@ -111,7 +111,7 @@ def time_render(pairs: int):
 
     def rt_hook(ray_origins, ray_directions, vertices, faces, device):
         tris = vertices.numpy()[faces.numpy()]
-        return torch.from_numpy(warp_oracle.ray_triangle_depth(ray_directions.numpy(), tris))
+        return torch.from_numpy(warp_oracle.ray_triangle_depth_c(ray_directions.numpy(), tris))
 
     fwu._warp_initialized = True
     fwu._ray_triangle_intersection_func = rt_hook
@@ -180,11 +180,18 @@ def main():
     if "dit" in args.what:
         res["dit"] = [time_dit(args.blocks, dt) for dt in dts]
         print(json.dumps(res["dit"]), flush=True)
+        OUT.write_text(json.dumps(res, indent=1))
     if "render" in args.what:
         res["render"] = time_render(args.pairs)
         print(json.dumps(res["render"]), flush=True)
+        OUT.write_text(json.dumps(res, indent=1))
     if "tokenizer" in args.what:
-        res["tokenizer"] = [time_tokenizer(tuple(int(v) for v in args.clip.split(",")), dt) for dt in dts]
+        res["tokenizer"] = []
+        for dt in dts:
+            try:
+                res["tokenizer"].append(time_tokenizer(tuple(int(v) for v in args.clip.split(",")), dt))
+            except NotImplementedError as e:  # torch 2.10 CPU: "avg_pool3d_out_frame" not implemented for 'BFloat16' (CausalHybridDownsample3d, layers3d.py:222)
+                res["tokenizer"].append(dict(dtype=str(dt).replace("torch.", ""), error=f"the reference's modules do not run in this dtype on CPU: {e}"))
         print(json.dumps(res["tokenizer"]), flush=True)
     OUT.write_text(json.dumps(res, indent=1))
     print("wrote", OUT)
