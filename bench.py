@@ -111,21 +111,25 @@ def cpu_baseline_render(threads: int):
     w2c = np.stack([np.eye(4, dtype=np.float32)] * 2)
     w2c[:, 0, 3] = (0.1, 0.11)
     out = {}
+    pairs = 8  # ~3 s + ~9 s on the GPU box's host
     for fg in (False, True):
         t0 = time.perf_counter()
-        warp_oracle.forward_warp(np.stack([img] * 2), np.concatenate([rel] * 2), np.concatenate([pts] * 2), w2c, np.stack([K] * 2),
-                                 foreground_masking=fg, boundary_mask=np.concatenate([bnd[:, 0]] * 2) if fg else None,
-                                 ray_triangle_fn=warp_oracle.ray_triangle_depth_c if fg else None)
+        for j in range(pairs):
+            w2c[:, 0, 3] = (0.3 * (2 * j) / 31, 0.3 * (2 * j + 1) / 31)
+            warp_oracle.forward_warp(np.stack([img] * 2), np.concatenate([rel] * 2), np.concatenate([pts] * 2), w2c, np.stack([K] * 2),
+                                     foreground_masking=fg, boundary_mask=np.concatenate([bnd[:, 0]] * 2) if fg else None,
+                                     ray_triangle_fn=warp_oracle.ray_triangle_depth_c if fg else None)
         dt = time.perf_counter() - t0
-        out["foreground_masking" if fg else "plain"] = dict(value=round(43.2e6 * 2 / dt / 1e9, 4), unit="GB/s", ms_per_item=round(dt / 2 * 1e3, 1), seconds=round(dt, 2))
-    out.update(cores=threads, kind="port", sample="oracle/warp_oracle.py (numpy; ray x triangle in C), one pair of 704x1280 items of the bench scene, 43.2 MB algorithmic per item")
+        out["foreground_masking" if fg else "plain"] = dict(value=round(43.2e6 * 2 * pairs / dt / 1e9, 4), unit="GB/s", ms_per_item=round(dt / (2 * pairs) * 1e3, 1),
+                                                              seconds=round(dt, 2))
+    out.update(cores=threads, kind="port", sample=f"oracle/warp_oracle.py (numpy; ray x triangle in C, OpenMP), {pairs} reference pairs = {2 * pairs} items of 704x1280 of the bench scene "
+                                                  f"(camera sliding left), 43.2 MB algorithmic per item")
     return out
 
 
 def cpu_baseline_tokenizer(threads: int):
-    """Tokenizer leg: oracle/tokenizer_oracle.py ("port", fp32 torch on the host) encode + decode of a 9 x 352 x 640 clip at channels = 128 - 1/32 of
-    the benchmark clip's latent volume (2 of 16 latent frames x 1/4 of the pixels; the attention share shrinks with the pixel count, so the
-    extrapolation by latent volume flatters the CPU slightly). The reference's own modules on CPU: profiles/r4_cpu_reference.json."""
+    """Tokenizer leg: oracle/tokenizer_oracle.py ("port", fp32 torch on the host) encode + decode of a 17 x 704 x 1280 clip at channels = 128 = 3/16 of
+    the benchmark clip's latent volume at its full resolution. The reference's own modules on CPU: profiles/r4_cpu_reference.json."""
     from oracle import tokenizer_oracle as tok
     from gen3c_amd.tokenizer import CausalVideoTokenizerNet
     torch.set_num_threads(threads)
@@ -134,7 +138,7 @@ def cpu_baseline_tokenizer(threads: int):
     sd = {}
     for k, shape in keys.items():
         sd[k] = (torch.rand(shape, generator=g) + 0.5) if k.endswith("norm.weight") else (torch.randn(shape, generator=g) * (0.05 if k.endswith(".bias") else (1.0 / max(1, int(np.prod(shape[1:])))) ** 0.5))
-    T, H, W = 9, 352, 640
+    T, H, W = 17, 704, 1280  # 3 of the 16 latent frames at the full resolution (the 14 080-pixel spatial attention included): ~10 + ~14 s
     x = torch.rand(1, 3, T, H, W, generator=g) * 2 - 1
     frac = (1 + (T - 1) / 8) * H * W / (16 * 704 * 1280)
     out = {}
@@ -237,8 +241,9 @@ def stage_rooflines(dev):
     gbs = 43.2e6 / (per_item * 1e-3) / 1e9
     traffic = traffic_source = None  # memory-side bytes per item: QUOTED from the committed rocprofv3 PMC passes of this configuration
     try:
-        tj = json.loads((ROOT / "profiles" / "r3_render_traffic.json").read_text())
-        traffic, traffic_source = tj["traffic_bytes_per_item"], "profiles/r3_render_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
+        tf = next(f for f in ("r4_render_traffic.json", "r3_render_traffic.json") if (ROOT / "profiles" / f).exists())  # the latest committed PMC passes
+        tj = json.loads((ROOT / "profiles" / tf).read_text())
+        traffic, traffic_source = tj["traffic_bytes_per_item"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
     except Exception:
         pass
     out["roofline_render"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(gbs, 1), frac=round(gbs / 8000.0, 4), ms_per_item=round(per_item, 4),
@@ -629,7 +634,7 @@ def main():
         m0 = self_attn[0][0]
         kname = m0.get("kernel") or _lib.load().g3_flash_attn_kernel_name(m0["Sq"], m0["Skv"], m0["B"], m0["H"]).decode()
         traffic = traffic_source = None  # HBM bytes per launch: QUOTED from the committed rocprofv3 PMC passes of this kernel at this shape
-        for tf in ("r3_attn_traffic.json", "r2_attn_traffic.json", "r1_attn_traffic.json"):
+        for tf in ("r4_attn_traffic.json", "r3_attn_traffic.json", "r2_attn_traffic.json", "r1_attn_traffic.json"):
             try:
                 tj = json.loads((ROOT / "profiles" / tf).read_text())
                 same_kernel = tj["kernel"].replace(" ", "").split("<")[0] == kname.replace(" ", "").split("<")[0]

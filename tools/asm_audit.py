@@ -169,6 +169,60 @@ def audit_gemm_w4(asm_text: str):
     return findings
 
 
+def audit_attn_d512(asm_text: str):
+    """attention_d512.hip (round 4): all 256 AGPRs hold the O^T accumulators and belong to the asm statements from the zeroing prologue to the
+    epilogue's reads - NO compiler-generated instruction of the kernel may name an AGPR (hipcc, left alone, parks the score accumulators in
+    a[0:31]: exactly where block (0, 0) lives); no scratch anywhere (a reload's compiler-inserted vmcnt(0) would also drain the tile's LDS-DMA);
+    between a hand-issued ds_read_b128 and the hand-counted lgkmcnt wait that retires it nothing else may name its destination registers."""
+    findings, body, cur = [], [], False
+    for ln in asm_text.split("\n"):
+        if re.match(r"^_ZN12_GLOBAL__N_1\d+spatial_attn_d512_kernel\w*:", ln):
+            cur = True
+        elif cur:
+            body.append(ln)
+            if ln.startswith(".Lfunc_end"):
+                break
+    if not body:
+        return ["attention_d512: kernel not found in the assembly"]
+    in_asm, pending, n_reads, n_mfma = False, {}, 0, 0
+    for i, l in enumerate(body):
+        t = l.strip()
+        if "ASMSTART" in t:
+            in_asm = True
+            continue
+        if "ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t[0] in ";.":
+            continue
+        n_mfma += t.startswith("v_mfma")
+        if t.startswith("scratch_"):
+            findings.append(f"attention_d512: line {i}: scratch access `{t}`")
+        if in_asm and t.startswith("ds_read_b128"):
+            n_reads += 1
+            for r in regs(t.split()[1].rstrip(",")):
+                pending[r] = i
+            continue
+        if in_asm and t.startswith("s_waitcnt lgkmcnt"):
+            n = int(re.search(r"lgkmcnt\((\d+)\)", t).group(1))
+            lines = sorted(set(pending.values()))
+            keep = set(lines[len(lines) - n:]) if n > 0 else set()
+            pending = {r: li for r, li in pending.items() if li in keep}
+            continue
+        if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+            pending = {}
+        for tok in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+            if regs(tok) & set(pending):
+                findings.append(f"attention_d512: line {i}: `{t}` touches an in-flight ds_read destination")
+                break
+        if not in_asm and re.search(r"\ba\[\d+:\d+\]|\ba\d+\b", t):
+            findings.append(f"attention_d512: line {i}: compiler-generated `{t}` touches an asm-owned AGPR")
+    print(f"attention_d512: {n_reads} hand-counted ds_reads, {n_mfma} MFMAs audited (asm-owned a0..a255, no scratch)")
+    if n_mfma != 128 or n_reads < 64:
+        findings.append(f"attention_d512: expected 128 MFMAs per tile body and >= 64 hand-issued fragment reads, found {n_mfma} / {n_reads}")
+    return findings
+
+
 def main():
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "attention.s"
@@ -185,6 +239,13 @@ def main():
             print(r.stderr)
             sys.exit(2)
         findings += audit_gemm_w4(out2.read_text())
+        out3 = Path(td) / "attention_d512.s"
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
+                            str(ROOT / "gen3c_amd" / "csrc" / "attention_d512.hip"), "-o", str(out3)], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr)
+            sys.exit(2)
+        findings += audit_attn_d512(out3.read_text())
     for f in findings:
         print("FINDING:", f)
     print("asm audit:", "clean" if not findings else f"{len(findings)} finding(s)")

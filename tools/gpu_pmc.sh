@@ -11,5 +11,5 @@ pass write WRITE_SIZE
 pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pass grbm GRBM_GUI_ACTIVE
 cd $ROOTD
-python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc_summary.csv flash_attn gemm_bf16 > gpurun_out/pmc_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc_summary.csv flash_attn gemm_bf16 spatial_attn > gpurun_out/pmc_summary.txt 2>&1
 cat gpurun_out/pmc_summary.txt | head -80

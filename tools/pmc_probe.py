@@ -29,4 +29,14 @@ for (M, N, K, epi) in [(56320, 12288, 4096, 0), (56320, 16384, 4096, 1), (56320,
         ops.gemm_nt(a, w, out=o, epilogue=epi, **kw)
     torch.cuda.synchronize()
     del a, w, gate, res, o
+# round 4: the tokenizer's d = 512 flash attention at the benchmark shape (16 frames x 14 080 pixels)
+from gen3c_amd import _lib  # noqa: E402
+T, HW, C = 16, 14080, 512
+q5, k5, v5 = (torch.randn(T, HW, C, device=dev).to(torch.bfloat16) for _ in range(3))
+vT5 = v5.reshape(T * HW, C).t().contiguous()
+o5 = torch.empty_like(q5)
+for _ in range(2):
+    _lib.check(_lib.load().g3_spatial_attn_d512_bf16(q5.data_ptr(), k5.data_ptr(), vT5.data_ptr(), T * HW, HW, o5.data_ptr(), T, HW, C ** -0.5,
+                                                     torch.cuda.current_stream().cuda_stream), "g3_spatial_attn_d512_bf16")
+torch.cuda.synchronize()
 print("done")

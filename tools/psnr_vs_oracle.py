@@ -99,11 +99,20 @@ def main(argv=None) -> int:
     common = dict(num_steps=args.num_steps, guidance=args.guidance, num_blocks=net.num_blocks, num_heads=net.num_heads, seed=args.seed, fps=float(args.fps))
     bfr = lambda x: x.to(torch.bfloat16).float()
     videos = {}
+    from oracle import tokenizer_oracle
+    import time
+    if H * W >= 352 * 640:  # the vendor's fp32 conv3d falls back to a naive kernel at these sizes: the oracle's per-tap matmul form (equal: tests/test_tokenizer_oracle_golden.py)
+        tokenizer_oracle.CONV_IMPL = "taps"
     with torch.no_grad():
         for name, dt in (("fp32", torch.float32), ("ref", torch.bfloat16)):
+            torch.cuda.empty_cache()
+            t_chain = time.perf_counter()
             v = chain_oracle.generate_chunk(dit_sd, tok_sd, mean, std, bfr(image), bfr(renders), bfr(masks), prompt.float(), None if negp is None else negp.float(),
                                             xt.float().to(dev), net_dtype=dt, **common)
             videos[name] = np.round(v.clamp(0, 1).cpu().numpy() * 255.0) / 255.0 if name == "ref" else v.cpu().numpy()  # the reference writes uint8 frames too
+            del v
+            print(f"[psnr_vs_oracle] oracle chain '{name}' took {time.perf_counter() - t_chain:.1f} s", flush=True)
+    tokenizer_oracle.CONV_IMPL = "torch"
     p_hip, p_ref = psnr_per_frame(hip, videos["fp32"]), psnr_per_frame(videos["ref"], videos["fp32"])
     delta = p_hip - p_ref
     worst = float(delta.min())
