@@ -428,9 +428,10 @@ class RunGuard:
 
     def _emit(self, error: str):
         with self._lock:
-            if self._emitted:
-                time.sleep(30)  # the other thread is printing / leaving
-            self._emitted = True
+            first, self._emitted = not self._emitted, True
+        if not first:
+            time.sleep(30)  # another thread of this rank is printing the line and leaving
+            return
         line = dict(self.base)
         prog = {k: v for k, v in self.progress.items()}
         line.update(value=None, ms_per_step=None, error=error, failed_phase=self.phase, progress=prog)

@@ -11,12 +11,12 @@ and report, per frame, PSNR(hip, fp32), PSNR(ref, fp32) and their difference. Ex
 The rendered buffers are shared by the three chains: the renderer's masks / indices are bit-exact against the reference on their own
 (tests/test_render_gpu.py), so this isolates the tokenizer + DiT + sampler numerics the 0.1 dB is about.
 
-  python tools/psnr_vs_oracle.py --checkpoint_dir checkpoints [--num_steps 35] [--oracle_blocks 28] [--json out.json]
+  python tools/psnr_vs_oracle.py --checkpoint_dir checkpoints [--num_steps 35] [--json out.json]
   python tools/psnr_vs_oracle.py --random_init --tiny --height 64 --width 96 --num_steps 3        # what tests/test_cli_gpu.py runs
 
-Cost at full size: the oracle chains are plain torch - one fp32 DiT forward at 56 320 tokens takes ~2 min on an MI355X (attention scores are
-materialised per head), so `--num_steps 35` is ~5 h for both chains; `--num_steps 3` (the Karras schedule of 3 steps) ~25 min. The product chain runs
-the same number of steps. Test infrastructure: imports oracle/, never imported by gen3c_amd/."""
+Cost at full size (measured, profiles/r4_psnr_fullsize.json: random weights, 1 step): each oracle chain - three tokenizer encodes, two 28-block DiT forwards at 56 320
+tokens with the attention scores materialised per head, one decode - takes ~65 s on an MI355X's torch, i.e. `--num_steps 35` is ~1 h for both chains and `--num_steps 3` ~5 min.
+Test infrastructure: imports oracle/, never imported by gen3c_amd/."""
 from __future__ import annotations
 
 import argparse
