@@ -209,3 +209,25 @@ def test_run_guard_prints_a_null_value_line_when_a_phase_overruns():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["value"] is None and line["n_gpus"] == 8 and line["failed_phase"] == "timed" and "deadline" in line["error"]
     assert line["progress"]["candidate"] == [4, "w4b", "local_first"]
+
+
+def test_autotune_failure_agreement_over_gloo_world2():
+    """The N > 1 agreement protocol of bench.autotune_cp over a REAL 2-rank gloo process group (CPU): candidate (4, w4b, local_first) raises on rank 1
+    only, BEFORE its step (rank 0 would otherwise enter the step's exchange alone and hang); candidate (2, wave8, gather_first) raises on both ranks
+    after the exchange. Both ranks must finish, drop exactly these two candidates, time the other 14 and configure the same winner."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, G3_BENCH_INJECT="autotune:4,w4b,local_first:1", WORKER_FAIL_IN_STEP="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(ROOT / "tests" / "_autotune_gloo_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    outs = sorted((json.loads(l.split("WORKER ", 1)[1]) for l in r.stdout.splitlines() if "WORKER " in l), key=lambda o: o["rank"])
+    assert len(outs) == 2
+    for o in outs:
+        assert o["n_table"] == 14 and sorted(map(tuple, o["failed"])) == [(2, "wave8", "gather_first"), (4, "w4b", "local_first")]
+    assert outs[0]["best"] == outs[1]["best"] and outs[0]["cfg"] == outs[1]["cfg"] and outs[0]["best"] is not None
