@@ -231,3 +231,25 @@ def test_autotune_failure_agreement_over_gloo_world2():
     for o in outs:
         assert o["n_table"] == 14 and sorted(map(tuple, o["failed"])) == [(2, "wave8", "gather_first"), (4, "w4b", "local_first")]
     assert outs[0]["best"] == outs[1]["best"] and outs[0]["cfg"] == outs[1]["cfg"] and outs[0]["best"] is not None
+
+
+def test_run_guard_relays_a_remote_failure_over_gloo_world2():
+    """RunGuard over a real 2-rank gloo group (CPU): rank 1 raises in its timed phase, rank 0 is stuck in an all-reduce rank 1 never joins. Rank 0 must
+    print ONE JSON line - value null, the phase, rank 1's exception, the chosen configuration - and the job must end within seconds, not at a timeout."""
+    import json
+    import socket
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(ROOT / "tests" / "_runguard_gloo_worker.py")], capture_output=True, text=True, timeout=300, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0 and "UNREACHABLE" not in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["failed_phase"] == "timed" and "rank 1" in out["error"] and "HIP error on rank 1" in out["error"]
+    assert out["progress"]["cp"]["chosen"]["head_groups"] == 4 and took < 120
