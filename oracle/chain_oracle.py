@@ -62,9 +62,16 @@ def generate_chunk(dit_sd: Dict[str, torch.Tensor], tok_sd: Dict[str, torch.Tens
     x = xt.to(dev, f32)
     gt_in = gt.to(torch.bfloat16).to(f32)  # the latent condition is handed over in bf16 (tensor_kwargs, model_v2w.py:121-128)
     for i in range(num_steps):
-        # denoise_step calls net_fn twice: with the pose (conditional) and with zeros (unconditional, model_gen3c.py:126-127)
-        x = sampler_oracle.denoise_step(lambda xx, tt, pp: f_cond(xx, tt, pp) if bool(pp.abs().sum() > 0) else f_unc(xx, tt, pp),
-                                        x, i, gt_in, ind, pose, num_steps, guidance, 0.001, seed)
+        # denoise_step calls net_fn exactly twice per step, in this order: with the pose (conditional branch, the prompt's context), then with
+        # zeros (unconditional branch, the negative prompt's context; model_v2w.py:137-141, model_gen3c.py:126-127)
+        calls = []
+
+        def net_fn(xx, tt, pp):
+            calls.append(1)
+            return (f_cond if len(calls) == 1 else f_unc)(xx, tt, pp)
+
+        x = sampler_oracle.denoise_step(net_fn, x, i, gt_in, ind, pose, num_steps, guidance, 0.001, seed)
+        assert len(calls) == 2
     if return_latent:
         return x
     y = tok.decode(tsd, (x / 0.5).to(net_dtype), mean, std).to(f32)

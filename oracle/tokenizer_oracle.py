@@ -94,10 +94,13 @@ def temporal_attn(x: torch.Tensor, sd: SD, pre: str) -> torch.Tensor:
 
 def hybrid_downsample(x: torch.Tensor, sd: SD, pre: str) -> torch.Tensor:
     """CausalHybridDownsample3d(spatial_down=True, temporal_down=True) (layers3d.py:185-234)."""
+    # (pooling evaluated in fp32 and cast back: identical for fp32 inputs; for bf16 inputs it is what a bf16 kernel computes - fp32 accumulation, one
+    # rounding - and torch's CPU build has no bf16 avg_pool3d at all)
+    pool = lambda v, k: F.avg_pool3d(v.float(), k, k).to(v.dtype)
     x = F.pad(x, (0, 1, 0, 1, 0, 0))
-    x = causal_conv3d(x, sd, f"{pre}.conv1", stride=(1, 2, 2)) + F.avg_pool3d(x, (1, 2, 2), (1, 2, 2))
+    x = causal_conv3d(x, sd, f"{pre}.conv1", stride=(1, 2, 2)) + pool(x, (1, 2, 2))
     x = torch.cat([x[:, :, :1], x], dim=2)  # replication_pad
-    x = causal_conv3d(x, sd, f"{pre}.conv2", stride=(2, 1, 1)) + F.avg_pool3d(x, (2, 1, 1), (2, 1, 1))
+    x = causal_conv3d(x, sd, f"{pre}.conv2", stride=(2, 1, 1)) + pool(x, (2, 1, 1))
     return causal_conv3d(x, sd, f"{pre}.conv3")
 
 
