@@ -178,11 +178,11 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
 
     for (int t = 0; t < nt; ++t) {
         // ================= phase A: S^T = K . Q^T for this wave's 32 query rows, online softmax, P -> LDS
-        f32x16 S[2];
+        f32x16 S[2], S2[2];  // two accumulator sets per key block (even / odd dim steps): four independent MFMA chains instead of two
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[mb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) S[mb][r] = S2[mb][r] = 0.f;
         {
             // 16 groups of {2 dim steps x 2 key blocks} = 4 MFMAs; the next group's four K fragments are read while this group multiplies.
             // sched_barrier pins the group order: left alone hipcc hoists all 64 fragment reads (256 registers) and spills the Q slice.
@@ -204,16 +204,28 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
                     a5_lds_wait<0>();
                 }
 #pragma unroll
+#ifdef G3_AB_D512_TWO_CHAINS  // (A/B: the first form - the two key blocks' accumulators only, every MFMA depends on the one two before it)
                 for (int j = 0; j < 4; ++j) a5_mfma_vgpr(S[j & 1], kf[grp & 1][j], qf[2 * grp + (j >> 1)]);
+#else
+                for (int j = 0; j < 4; ++j) a5_mfma_vgpr((j >> 1) ? S2[j & 1] : S[j & 1], kf[grp & 1][j], qf[2 * grp + (j >> 1)]);
+#endif
                 // V^T(t) streams into its buffer (free since the barrier that ended tile t - 1) under these MFMAs: two 1-KiB pieces per group in
                 // the first half of the phase, so that the last one has most of a microsecond to land before barrier #1
+#ifdef G3_AB_D512_DMA_SPREAD  // (A/B: one piece behind every group instead of two behind each of the first eight)
+                dma_v_piece(std::integral_constant<int, grp>{}, t * KV5);
+#else
                 if constexpr (grp < 8) {
                     dma_v_piece(std::integral_constant<int, 2 * grp>{}, t * KV5);
                     dma_v_piece(std::integral_constant<int, 2 * grp + 1>{}, t * KV5);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(S[0]), "+v"(S[1]));  // MFMA results -> VALU (the statements above are opaque to hipcc's hazard recogniser)
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(S[0]), "+v"(S[1]), "+v"(S2[0]), "+v"(S2[1]));  // MFMA results -> VALU (the statements above are opaque to hipcc's hazard recogniser)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[mb][r] += S2[mb][r];
         }
         // S[mb][r] belongs to key = 64 t + 32 mb + 16 (r >> 3) + 8 g + (r & 7), query = l31 (after the bit-2/3 row permutation)
         float mx = S[0][0];
@@ -284,12 +296,16 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
                 const bf16x8(&pp)[4] = pf[s_ & 1];
                 a5_pv_group<db>(vf[grp & 1], pp[0], pp[1], pp[2], pp[3]);
                 // K(t + 1) streams into the K buffer (free since barrier #1) under these MFMAs
+#ifdef G3_AB_D512_DMA_SPREAD
+                if (has_next) dma_k_piece(std::integral_constant<int, grp>{}, (t + 1) * KV5);
+#else
                 if constexpr (grp < 8) {
                     if (has_next) {
                         dma_k_piece(std::integral_constant<int, 2 * grp>{}, (t + 1) * KV5);
                         dma_k_piece(std::integral_constant<int, 2 * grp + 1>{}, (t + 1) * KV5);
                     }
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
