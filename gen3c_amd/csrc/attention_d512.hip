@@ -28,6 +28,11 @@ constexpr int BQ5 = 128;   // query rows per workgroup
 constexpr int KV5 = 64;    // keys per tile
 constexpr int NT5 = 256;   // threads (4 waves, one per SIMD)
 constexpr float RESCALE_THR = 8.0f;
+// timing ablations (tools/flash512_ab.py; results are garbage): -DG3_AB_D512_ABLATE=<bits>  1: no LDS-DMA pieces, 2: no softmax arithmetic (exp2 / sums / max),
+// 4: phase A does not read its K fragments from LDS, 8: phase B does not read V^T / P fragments, 16: no barriers
+#ifndef G3_AB_D512_ABLATE
+#define G3_AB_D512_ABLATE 0
+#endif
 
 struct Attn512Params {
     const bf16_t* Q;   // [frames][hw][512]
@@ -73,6 +78,7 @@ template <int OFF> G3_DEVICE void a5_lds_read(bf16x8& dst, uint32_t addr) {
 template <int N> G3_DEVICE void a5_lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 // one LDS-DMA piece (1 KiB = 64 lanes x 16 B, lane-linear in LDS): destination in M0, source = wave-uniform base (SGPR pair) + 32-bit per-lane offset
 G3_DEVICE void a5_dma_piece(uint32_t lds_dst, uint32_t lane_off, const char* base) {
+    if (G3_AB_D512_ABLATE & 1) return;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
 }
 // the 4 MFMAs of one (k-step, dim block DB) group: V^T fragment x the four query blocks' P fragments
@@ -178,37 +184,41 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
 
     for (int t = 0; t < nt; ++t) {
         // ================= phase A: S^T = K . Q^T for this wave's 32 query rows, online softmax, P -> LDS
-        f32x16 S[2], S2[2];  // two accumulator sets per key block (even / odd dim steps): four independent MFMA chains instead of two
+        f32x16 S[2];  // (two more accumulator sets = four independent MFMA chains measured the same: 6.236 vs 6.227 ms, profiles/r4_flash512_ab.txt)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[mb][r] = S2[mb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) S[mb][r] = 0.f;
         {
             // 16 groups of {2 dim steps x 2 key blocks} = 4 MFMAs; the next group's four K fragments are read while this group multiplies.
             // sched_barrier pins the group order: left alone hipcc hoists all 64 fragment reads (256 registers) and spills the Q slice.
-            bf16x8 kf[2][4];
+#ifdef G3_AB_D512_PREFETCH2  // (A/B) K fragments two groups ahead (three buffers)
+            constexpr int NKB = 3;
+#else
+            constexpr int NKB = 2;
+#endif
+            bf16x8 kf[NKB][4];
             auto rd = [&](auto GRP, bf16x8 (&dst)[4]) {
                 constexpr int grp = decltype(GRP)::value;
                 static_for<0, 4>([&](auto J) {
                     constexpr int j = J.value;
-                    a5_lds_read<(grp >> 2) * 256 + (j & 1) * 32768>(dst[j], kaddr[2 * (grp & 3) + (j >> 1)]);
+                    if (!(G3_AB_D512_ABLATE & 4) || grp == 0) a5_lds_read<(grp >> 2) * 256 + (j & 1) * 32768>(dst[j], kaddr[2 * (grp & 3) + (j >> 1)]);
+                    else dst[j] = kf[0][j];
                 });
             };
             rd(std::integral_constant<int, 0>{}, kf[0]);
+            if constexpr (NKB == 3) rd(std::integral_constant<int, 1>{}, kf[1]);
             static_for<0, 16>([&](auto GRP) {
                 constexpr int grp = GRP.value;
-                if constexpr (grp + 1 < 16) {
-                    rd(std::integral_constant<int, grp + 1>{}, kf[(grp + 1) & 1]);
-                    a5_lds_wait<4>();  // this group's four fragments have landed (the four just issued are still in flight)
+                constexpr int ahead = NKB - 1;
+                if constexpr (grp + ahead < 16) {
+                    rd(std::integral_constant<int, grp + ahead>{}, kf[(grp + ahead) % NKB]);
+                    a5_lds_wait<4 * ahead>();  // this group's four fragments have landed (the younger ones are still in flight)
                 } else {
-                    a5_lds_wait<0>();
+                    a5_lds_wait<4 * (15 - grp)>();
                 }
 #pragma unroll
-#ifdef G3_AB_D512_TWO_CHAINS  // (A/B: the first form - the two key blocks' accumulators only, every MFMA depends on the one two before it)
-                for (int j = 0; j < 4; ++j) a5_mfma_vgpr(S[j & 1], kf[grp & 1][j], qf[2 * grp + (j >> 1)]);
-#else
-                for (int j = 0; j < 4; ++j) a5_mfma_vgpr((j >> 1) ? S2[j & 1] : S[j & 1], kf[grp & 1][j], qf[2 * grp + (j >> 1)]);
-#endif
+                for (int j = 0; j < 4; ++j) a5_mfma_vgpr(S[j & 1], kf[grp % NKB][j], qf[2 * grp + (j >> 1)]);
                 // V^T(t) streams into its buffer (free since the barrier that ended tile t - 1) under these MFMAs: two 1-KiB pieces per group in
                 // the first half of the phase, so that the last one has most of a microsecond to land before barrier #1
 #ifdef G3_AB_D512_DMA_SPREAD  // (A/B: one piece behind every group instead of two behind each of the first eight)
@@ -221,19 +231,17 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             });
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(S[0]), "+v"(S[1]), "+v"(S2[0]), "+v"(S2[1]));  // MFMA results -> VALU (the statements above are opaque to hipcc's hazard recogniser)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[mb][r] += S2[mb][r];
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(S[0]), "+v"(S[1]));  // MFMA results -> VALU (the statements above are opaque to hipcc's hazard recogniser)
         }
         // S[mb][r] belongs to key = 64 t + 32 mb + 16 (r >> 3) + 8 g + (r & 7), query = l31 (after the bit-2/3 row permutation)
         float mx = S[0][0];
+        if (!(G3_AB_D512_ABLATE & 2)) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[0][r]);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[0][r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[1][r]);
-        mx = fmaxf(mx, wave_xor_f32(mx, 32)) * c;
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[1][r]);
+            mx = fmaxf(mx, wave_xor_f32(mx, 32)) * c;
+        }
         float alpha = 1.0f;
         if (mx > m_run + RESCALE_THR) {  // deferred rescale: the reference point moves only on a jump of more than 2^8
             alpha = __builtin_amdgcn_exp2f(m_run - mx);
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[mb][r], c, -m_run));
+                const float pv = (G3_AB_D512_ABLATE & 2) ? S[mb][r] : __builtin_amdgcn_exp2f(__builtin_fmaf(S[mb][r], c, -m_run));
                 psum += pv;
                 pb[2 * mb + (r >> 3)][r & 7] = f32_to_bf16(pv);
             }
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
             if (lane == 0) sFlag[wave] = 1;
         }
         G3_JITTER(wave + 1, t);
-        lds_dma_publish_barrier();  // P / alpha / flags visible; V^T(t) has landed; every wave is done reading K(t)
+        if (!(G3_AB_D512_ABLATE & 16)) lds_dma_publish_barrier();  // P / alpha / flags visible; V^T(t) has landed; every wave is done reading K(t)
         const bool has_next = t + 1 < nt;
 
         // ================= phase B: O^T[this wave's 128 dims][128 queries] += V^T . P^T
@@ -276,14 +284,18 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
             // (and, at a k-step boundary, its P fragments) is read while this group multiplies.
             bf16x8 pf[2][4], vf[2];
             auto rd_p = [&](auto S_, bf16x8 (&dst)[4]) {
-                static_for<0, 4>([&](auto QB) { a5_lds_read<(decltype(S_)::value * 4 + QB.value) * 1024>(dst[QB.value], paddr); });
+                static_for<0, 4>([&](auto QB) {
+                    if (!(G3_AB_D512_ABLATE & 8) || decltype(S_)::value == 0) a5_lds_read<(decltype(S_)::value * 4 + QB.value) * 1024>(dst[QB.value], paddr);
+                    else dst[QB.value] = pf[0][QB.value];
+                });
             };
             a5_lds_read<0>(vf[0], vaddr[0]);
             rd_p(std::integral_constant<int, 0>{}, pf[0]);
             static_for<0, 16>([&](auto GRP) {
                 constexpr int grp = GRP.value, s_ = grp >> 2, db = grp & 3;
                 if constexpr (grp + 1 < 16) {
-                    a5_lds_read<((grp + 1) & 3) * 32 * KV5 * 2>(vf[(grp + 1) & 1], vaddr[(grp + 1) >> 2]);
+                    if (!(G3_AB_D512_ABLATE & 8)) a5_lds_read<((grp + 1) & 3) * 32 * KV5 * 2>(vf[(grp + 1) & 1], vaddr[(grp + 1) >> 2]);
+                    else vf[(grp + 1) & 1] = vf[grp & 1];
                     if constexpr (db == 3) {
                         rd_p(std::integral_constant<int, s_ + 1>{}, pf[(s_ + 1) & 1]);
                         a5_lds_wait<5>();
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(NT5, 1) void spatial_attn_d512_kernel(Attn512Params
             });
         }
         G3_JITTER(wave + 2, t);
-        lds_dma_publish_barrier();  // K(t+1) has landed and is visible; every wave is done with V^T(t), P(t), alpha(t)
+        if (!(G3_AB_D512_ABLATE & 16)) lds_dma_publish_barrier();  // K(t+1) has landed and is visible; every wave is done with V^T(t), P(t), alpha(t)
         if (moved) {  // reset for the next tile (the owner wave alone writes its flag / factors; read again only after the next barrier #1)
             if (g == 0) sAlpha[wave * 32 + l31] = 1.0f;
             if (lane == 0) sFlag[wave] = 0;
