@@ -177,3 +177,35 @@ def test_gen3c_inference_model_maps_requests_onto_the_persistent_model(gold):
     assert second.images.shape[0] == n - 1 and second.cameras_to_world.shape[0] == n - 1 and second.depths is None
     md = model.metadata()
     assert md["min_frames_per_request"] == 5 and md["max_frames_per_request"] == 500 and md["inference_resolution"] == [(32, 16)] and md["requires_seeding"]
+
+
+def test_pad_trim_and_npz_round_trips_are_identities_property():
+    """Size-independent properties of the records (hypothesis): pad_to_frame_count(m) then trim_to_original_frame_count() restores every per-frame field;
+    the padding repeats the LAST entry; NPZ compression of depths / masks / 8-bit colours round-trips exactly."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(n=st.integers(1, 9), extra=st.integers(0, 7), seed=st.integers(0, 10_000))
+    def run(n, extra, seed):
+        rs = np.random.RandomState(seed)
+        req = api.InferenceRequest(request_id="p", timestamps=rs.rand(n).astype(np.float32), cameras_to_world=rs.randn(n, 3, 4).astype(np.float32),
+                                   focal_lengths=rs.rand(n, 2).astype(np.float32) + 1, principal_points=rs.rand(n, 2).astype(np.float32),
+                                   resolutions=np.tile([[64, 32]], (n, 1)))
+        before = {k: getattr(req, k).copy() for k in ("timestamps", "cameras_to_world", "focal_lengths", "principal_points", "resolutions")}
+        req.pad_to_frame_count(n + extra)
+        assert len(req) == n + extra and req.frame_count_without_padding == n
+        for k, v in before.items():
+            got = getattr(req, k)
+            assert np.array_equal(got[:n], v) and all(np.array_equal(got[i], v[-1]) for i in range(n, n + extra))
+        req.trim_to_original_frame_count()
+        assert all(np.array_equal(getattr(req, k), v) for k, v in before.items())
+        h, w = int(rs.randint(1, 6)), int(rs.randint(1, 7))
+        depth = rs.rand(n, h, w).astype(np.float32) * 10
+        mask = rs.rand(n, h, w) > 0.5
+        col = rs.randint(0, 256, (n, h, w, 3)).astype(np.float32) / 255.0
+        F = api.CompressionFormat.NPZ
+        assert np.array_equal(api.decompress_buffer(api.compress_images(depth, F, is_depth=True), F, is_depth=True), depth)
+        assert np.array_equal(api.decompress_buffer(api.compress_images(mask, F, is_bool=True), F, is_bool=True), mask)
+        assert np.array_equal(api.decompress_buffer(api.compress_images(col, F), F), (col * 255.0).astype(np.uint8))
+
+    run()
