@@ -155,6 +155,95 @@ def cpu_baseline_tokenizer(threads: int):
     return out
 
 
+def parse_pmc_csv(text: str, kernel_substr: str, counter: str):
+    """Mean Counter_Value of `counter` over the dispatches of kernels whose name contains `kernel_substr` in a rocprofv3 counter_collection.csv."""
+    import csv
+    import io
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(io.StringIO(text)) if r.get("Counter_Name") == counter and kernel_substr in r.get("Kernel_Name", "")]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def sum_pmc_csv(text: str, kernel_substrs, counter: str) -> float:
+    """Sum of `counter` over all dispatches of kernels whose name contains any of `kernel_substrs`."""
+    import csv
+    import io
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(io.StringIO(text))
+               if r.get("Counter_Name") == counter and any(k in r.get("Kernel_Name", "") for k in kernel_substrs))
+
+
+def _pmc_pass(counter: str, probe: str, extra_env: dict, timeout_s: int):
+    """One rocprofv3 pass (--kernel-trace --pmc <counter> only) over tools/<probe> in a child process, from /tmp -> text of its counter_collection.csv files."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists():
+        raise RuntimeError("rocprofv3 not found")
+    d = tempfile.mkdtemp(prefix="g3pmc_", dir="/tmp")
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, str(ROOT / "tools" / probe)],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **extra_env), capture_output=True, text=True, timeout=timeout_s)
+        files = list(Path(d).rglob("*counter_collection.csv"))
+        if r.returncode != 0 or not files:
+            raise RuntimeError(f"rocprofv3 --pmc {counter} over {probe} failed (rc {r.returncode})")
+        return "\n".join(f.read_text() for f in files)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_render_traffic(timeout_s: int = 150):
+    """`roofline_render.traffic` measured in this run: FETCH_SIZE and WRITE_SIZE passes over tools/bench_render_single.py restricted to the benchmarked configuration
+    (foreground masking; 4 renders x 32 items in the child process), summed over every renderer kernel (warp_* / mesh_*) and divided by the 128 items. Raw counters, no
+    correction factor: the renderer's loads are 4 B/lane, for which the guide gives no calibration (profiles/r3_render_traffic.json found FETCH_SIZE ~0.83x there)."""
+    try:
+        tot = 0.0
+        parts = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            kb = sum_pmc_csv(_pmc_pass(counter, "bench_render_single.py", {"G3_RENDER_ONLY_FG": "1"}, timeout_s), ("warp_", "mesh_"), counter)
+            if kb <= 0:
+                return None, f"no renderer dispatch in the {counter} pass"
+            parts[counter] = kb
+            tot += kb * 1000.0
+        return int(tot / 128), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/bench_render_single.py (foreground masking, 4 x 32 items "
+                                f"in a child process), all warp_* / mesh_* kernels, per item; raw counters (FETCH_SIZE {parts['FETCH_SIZE']:.4g} KB + WRITE_SIZE {parts['WRITE_SIZE']:.4g} KB) / 128")
+    except Exception as e:  # noqa: BLE001
+        return None, repr(e)
+
+
+def measure_attention_traffic(kernel_substr: str = "flash_attn_fwd_w4b", timeout_s: int = 150):
+    """`roofline.traffic` measured IN THIS RUN: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: one counter per
+    pass, nothing else, as MI355X_MICROARCH.md's HBM section prescribes) over tools/pmc_probe.py, which issues the benchmark's own self-attention launch
+    (S = 56 320, H = 32, B = 2, strided q / k views) twice in a child process on this box, from /tmp. bytes = FETCH_SIZE[KB] x 1000 x 2 (the guide's gfx950
+    correction: 16 B/lane coalesced reads are tallied at half size) + WRITE_SIZE[KB] x 1000. Returns (bytes per launch, description) or (None, why)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(exe).exists():
+        return None, "rocprofv3 not found"
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp", G3_PMC_ONLY="attn")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="g3pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, str(ROOT / "tools" / "pmc_probe.py")],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = list(Path(d).rglob("*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            v, n = parse_pmc_csv("\n".join(f.read_text() for f in files), kernel_substr, counter)
+            if v is None:
+                return None, f"no {kernel_substr} dispatch in the {counter} pass"
+            got[counter] = v
+        except Exception as e:  # noqa: BLE001 - the traffic entry must never hide the measurement
+            return None, f"rocprofv3 --pmc {counter}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = int(got["FETCH_SIZE"] * 1000 * 2 + got["WRITE_SIZE"] * 1000)
+    return total, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_probe.py = this launch in a child process; "
+                   f"FETCH_SIZE {got['FETCH_SIZE']:.4g} KB x 2 (gfx950 correction of the guide) + WRITE_SIZE {got['WRITE_SIZE']:.4g} KB")
+
+
 TOK_FIXTURE = ROOT / "tests" / "golden" / "tokenizer_fullsize_samples.npz"
 
 
@@ -246,8 +335,16 @@ def stage_rooflines(dev):
         traffic, traffic_source = tj["traffic_bytes_per_item"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
     except Exception:
         pass
+    traffic_quoted = traffic
+    del cache
+    torch.cuda.empty_cache()
+    measured, how = measure_render_traffic()
+    if measured is not None:
+        traffic, traffic_source = measured, how
+    elif traffic_source:
+        traffic_source += f" [in-run measurement unavailable: {how}]"
     out["roofline_render"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(gbs, 1), frac=round(gbs / 8000.0, 4), ms_per_item=round(per_item, 4),
-                                  traffic=traffic, traffic_source=traffic_source,
+                                  traffic=traffic, traffic_source=traffic_source, traffic_quoted=traffic_quoted,
                                   workload="cache render (project + splat + mesh occlusion + resolve), 704x1280 items, foreground masking, 43.2 MB algorithmic per item")
     return out
 
@@ -686,6 +783,14 @@ def main():
         })
         if cp_info is not None:
             out["cp"] = cp_info
+        if not args.no_extras and world == 1 and roof is not None and "w4b" in roof["kernel"] and (N_tok, args.blocks) == (56320, 28):
+            # the dominant kernel's memory-side traffic, measured now on this box instead of quoted from a committed file (the quoted figure stays as fallback)
+            measured, how = measure_attention_traffic()
+            if measured is not None:
+                out["roofline"]["traffic_quoted"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured, how
+            else:
+                out["roofline"]["traffic_source"] = (out["roofline"].get("traffic_source") or "") + f" [in-run measurement unavailable: {how}]"
         if not args.no_extras and world == 1:
             try:
                 out.update(stage_rooflines(dev))

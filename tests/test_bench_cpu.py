@@ -253,3 +253,15 @@ def test_run_guard_relays_a_remote_failure_over_gloo_world2():
     out = json.loads(lines[0])
     assert out["value"] is None and out["failed_phase"] == "timed" and "rank 1" in out["error"] and "HIP error on rank 1" in out["error"]
     assert out["progress"]["cp"]["chosen"]["head_groups"] == 4 and took < 120
+
+
+def test_pmc_csv_parser_means_the_named_kernels_counter():
+    import bench
+    hdr = '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+    row = lambda name, c, v: f'1,1,"Agent 2",1,2,2,64,5,"{name}",256,0,0,128,256,32,"{c}",{v},10,20\n'
+    text = hdr + row("void (anonymous namespace)::flash_attn_fwd_w4b_kernel<true>(AttnParams)", "FETCH_SIZE", 7.0e6) + \
+        row("void (anonymous namespace)::flash_attn_fwd_w4b_kernel<true>(AttnParams)", "FETCH_SIZE", 8.0e6) + \
+        row("void transpose_v_kernel(x)", "FETCH_SIZE", 1.0) + row("void (anonymous namespace)::flash_attn_fwd_w4b_kernel<true>(AttnParams)", "WRITE_SIZE", 4.0e6)
+    assert bench.parse_pmc_csv(text, "flash_attn_fwd_w4b", "FETCH_SIZE") == (7.5e6, 2)
+    assert bench.parse_pmc_csv(text, "flash_attn_fwd_w4b", "WRITE_SIZE") == (4.0e6, 1)
+    assert bench.parse_pmc_csv(text, "gemm", "FETCH_SIZE") == (None, 0)

@@ -18,7 +18,10 @@ w2cs = torch.eye(4, device=dev).repeat(1, F, 1, 1)
 w2cs[0, :, 0, 3] = torch.linspace(0, 0.3, F, device=dev)
 Ks = t(K)[None, None].expand(1, F, 3, 3).contiguous()
 import os
-for fg, overlap in ((False, 1), (True, 1)) + (((True, 0), (True, 1)) if os.environ.get("G3_RENDER_AB") else ()):
+CONFIGS = ((False, 1), (True, 1)) + (((True, 0), (True, 1)) if os.environ.get("G3_RENDER_AB") else ())
+if os.environ.get("G3_RENDER_ONLY_FG"):  # bench.py's in-run traffic passes: the benchmarked configuration only (4 renders x 32 items)
+    CONFIGS = ((True, 1),)
+for fg, overlap in CONFIGS:
     ops.set_option("render_overlap", overlap)
     cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
                                     input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from gen3c_amd import ops  # noqa: E402
 
+import os  # noqa: E402
+ONLY = os.environ.get("G3_PMC_ONLY", "")  # "attn": just the self-attention launch (bench.py's in-run traffic passes)
 dev = torch.device("cuda:0")
 S, H, B = 56320, 32, 2  # the benchmark's launch: conditional + unconditional branch as one B = 2 problem, q / k column views of the fused QKV buffer
 qkv = torch.randn(S * B, 3 * H * 128, device=dev).to(torch.bfloat16)
@@ -18,6 +20,9 @@ for _ in range(2):
     ops.flash_attn(q, k, vt, S, S, B, H, out=out)
 torch.cuda.synchronize()
 del q, k, qkv, vt, out
+if ONLY == "attn":
+    print("done")
+    sys.exit(0)
 for (M, N, K, epi) in [(56320, 12288, 4096, 0), (56320, 16384, 4096, 1), (56320, 4096, 16384, 2)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
