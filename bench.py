@@ -111,7 +111,7 @@ def cpu_baseline_render(threads: int):
     w2c = np.stack([np.eye(4, dtype=np.float32)] * 2)
     w2c[:, 0, 3] = (0.1, 0.11)
     out = {}
-    pairs = 8  # ~3 s + ~9 s on the GPU box's host
+    pairs = 4  # ~1.5 s + ~5 s on the GPU box's host
     for fg in (False, True):
         t0 = time.perf_counter()
         for j in range(pairs):
@@ -128,7 +128,7 @@ def cpu_baseline_render(threads: int):
 
 
 def cpu_baseline_tokenizer(threads: int):
-    """Tokenizer leg: oracle/tokenizer_oracle.py ("port", fp32 torch on the host) encode + decode of a 17 x 704 x 1280 clip at channels = 128 = 3/16 of
+    """Tokenizer leg: oracle/tokenizer_oracle.py ("port", fp32 torch on the host) encode + decode of a 9 x 704 x 1280 clip at channels = 128 = 2/16 of
     the benchmark clip's latent volume at its full resolution. The reference's own modules on CPU: profiles/r4_cpu_reference.json."""
     from oracle import tokenizer_oracle as tok
     from gen3c_amd.tokenizer import CausalVideoTokenizerNet
@@ -138,7 +138,7 @@ def cpu_baseline_tokenizer(threads: int):
     sd = {}
     for k, shape in keys.items():
         sd[k] = (torch.rand(shape, generator=g) + 0.5) if k.endswith("norm.weight") else (torch.randn(shape, generator=g) * (0.05 if k.endswith(".bias") else (1.0 / max(1, int(np.prod(shape[1:])))) ** 0.5))
-    T, H, W = 17, 704, 1280  # 3 of the 16 latent frames at the full resolution (the 14 080-pixel spatial attention included): ~10 + ~14 s
+    T, H, W = 9, 704, 1280  # 2 of the 16 latent frames at the full resolution (the 14 080-pixel spatial attention included): ~7 + ~11 s
     x = torch.rand(1, 3, T, H, W, generator=g) * 2 - 1
     frac = (1 + (T - 1) / 8) * H * W / (16 * 704 * 1280)
     out = {}
