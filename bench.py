@@ -75,20 +75,55 @@ def cpu_baseline(threads: int, blocks: int = 1):
     mask = torch.zeros(1, 1, T, Hh, Ww)
     ctx = torch.randn(1, M, 1024, generator=g) * 0.2
     N = T * (Hh // 2) * (Ww // 2)
-    reps = 1
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        for _ in range(reps):
-            dit_oracle.dit_forward(sd, x, torch.tensor([0.3]), ctx, mask, pose, torch.zeros(1, 1, 8 * Hh, 8 * Ww),
-                                   torch.tensor([24.0]), num_blocks=blocks, num_heads=H)
-    dt = time.perf_counter() - t0
-    flops = reps * dit_forward_flops(N, L=blocks)
-    rate = flops / dt
+    flops = dit_forward_flops(N, L=blocks)
     step_flops = 2 * dit_forward_flops(56320)
-    return dict(value=rate / step_flops, unit="denoise-steps/sec", cores=threads, kind="port",
-                seconds=round(dt, 2), blocks=blocks,
-                sample=f"oracle/dit_oracle.py fp32: {blocks} of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, measured "
-                       f"{dt:.1f}s = {rate/1e12:.3f} TFLOP/s; extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step); "
+
+    def run(sd_, cast):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            dit_oracle.dit_forward(sd_, cast(x), cast(torch.tensor([0.3])), cast(ctx), cast(mask), cast(pose), cast(torch.zeros(1, 1, 8 * Hh, 8 * Ww)),
+                                   torch.tensor([24.0]), num_blocks=blocks, num_heads=H)
+        return time.perf_counter() - t0
+
+    dt32 = run(sd, lambda t: t)
+    legs = {"fp32": dict(value=flops / dt32 / step_flops, tflops=round(flops / dt32 / 1e12, 3), seconds=round(dt32, 2))}
+    # The reference runs this network with bf16 parameters and activations (config/base/model.py:29 `precision="bfloat16"`): the same sample with the
+    # oracle's bf16 evaluation (= the reference's rounding points: bf16 Linear outputs, fp32 norm statistics, P rounded to bf16) is the CPU figure that
+    # corresponds to what the reference would do on these cores. A host without native bf16 GEMM kernels can be far slower in bf16 than in fp32 - a
+    # one-matmul probe decides whether the leg is worth its seconds.
+    def probe(dtype):
+        a, b = torch.randn(2048, D, generator=g).to(dtype), torch.randn(D, D, generator=g).to(dtype)
+        a @ b.t()
+        t0 = time.perf_counter()
+        a @ b.t()
+        return 2 * 2048 * D * D / (time.perf_counter() - t0) / 1e12
+    p32, p16 = probe(torch.float32), probe(torch.bfloat16)
+    note16 = f"one-GEMM probe on this host: bf16 {p16:.2f} vs fp32 {p32:.2f} TFLOP/s"
+    if p16 >= 0.5 * p32:
+        sd16 = {k_: (v_ if k_ == "pos_embedder.seq" else v_.to(torch.bfloat16)) for k_, v_ in sd.items()}
+        # attention of the bf16 leg through torch's fused CPU kernel (F.scaled_dot_product_attention in bf16) - what the reference's attention falls back
+        # to off-GPU and how profiles/r4_cpu_reference.json timed it; the oracle's own attention_sbhd materialises fp32 score matrices (a checker's
+        # form, 10x slower than any CPU path the reference would take). Timing leg only: the parity oracle is untouched.
+        def sdpa_sbhd(q, k, v):
+            qs, ks, vs = (t.permute(1, 2, 0, 3) for t in (q, k, v))  # b h s d
+            return torch.nn.functional.scaled_dot_product_attention(qs, ks, vs).permute(2, 0, 1, 3).reshape(q.shape[0], q.shape[1], -1)
+        keep = dit_oracle.attention_sbhd
+        dit_oracle.attention_sbhd = sdpa_sbhd
+        try:
+            dt16 = run(sd16, lambda t: t.to(torch.bfloat16))
+        finally:
+            dit_oracle.attention_sbhd = keep
+        legs["bf16"] = dict(value=flops / dt16 / step_flops, tflops=round(flops / dt16 / 1e12, 3), seconds=round(dt16, 2))
+    else:
+        note16 += " - bf16 leg skipped (no native bf16 GEMM on this host), value = the fp32 leg"
+    head = legs.get("bf16", legs["fp32"])
+    prec = "bf16" if "bf16" in legs else "fp32"
+    return dict(value=head["value"], unit="denoise-steps/sec", cores=threads, kind="port", precision=prec,
+                seconds=head["seconds"], blocks=blocks, legs=legs,
+                sample=f"oracle/dit_oracle.py: {blocks} of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, timed in fp32 "
+                       f"({dt32:.1f}s = {legs['fp32']['tflops']} TFLOP/s) and in bf16 = the reference's precision, attention through torch's fused CPU SDPA (" +
+                       (f"{legs['bf16']['seconds']}s = {legs['bf16']['tflops']} TFLOP/s" if "bf16" in legs else "skipped") + f"; {note16}); `value` = the {prec} leg, "
+                       f"extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step); "
                        f"per-block linearity of the extrapolation checked once: profiles/r3_cpu_baseline_linearity.txt")
 
 
@@ -270,7 +305,6 @@ def stage_rooflines(dev):
     from gen3c_amd.tokenizer import CausalVideoTokenizerNet
     out = {}
     net = CausalVideoTokenizerNet(channels=128, device=dev)
-    net.init_random(seed=0)
     net.init_random(seed=3)  # the weights of tests/test_fullsize_gpu.py::test_tokenizer_full_clip_vs_fp32_oracle
     x = tokenizer_bench_clip(dev)
     z = None
@@ -481,6 +515,27 @@ def autotune_cp(net, den, xt, cond, uncond, dev, dist, rank: int = 0, progress: 
     return best, table, failed
 
 
+class _FileErrorStore:
+    """set / check / get of ONE key through a file in the node's temp directory (RunGuard's fallback side channel)."""
+
+    def __init__(self, tag: str):
+        import tempfile
+        self.path = os.path.join(tempfile.gettempdir(), f"g3_bench_error_{tag}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}")
+
+    def set(self, key, msg):
+        tmp = f"{self.path}.{os.getpid()}"
+        with open(tmp, "w") as f:
+            f.write(msg)
+        os.replace(tmp, self.path)
+
+    def check(self, keys):
+        return os.path.exists(self.path)
+
+    def get(self, key):
+        with open(self.path, "rb") as f:
+            return f.read()
+
+
 class RunGuard:
     """The one multi-GPU run the driver makes must end with a JSON line whatever happens. One daemon thread per rank (N > 1 only):
       * a rank whose phase raised publishes the exception in the process group's key-value store (`fail`); every rank's thread polls the
@@ -500,6 +555,11 @@ class RunGuard:
             self.store = _get_default_store()
         except Exception:
             pass
+        if self.store is None and world > 1:
+            # (private torch API gone / no default group): without a side channel a failure on rank != 0 would never reach rank 0 and the job
+            # would end without a JSON line. One node, one /tmp: a file keyed by the rendezvous port does the same job.
+            self.store = _FileErrorStore(os.environ.get("MASTER_PORT", "0"))
+            print(f"bench.py: rank {rank}: no process-group store, RunGuard falls back to {self.store.path}", file=sys.stderr, flush=True)
         self._t = threading.Thread(target=self._watch, daemon=True)
         self._t.start()
 

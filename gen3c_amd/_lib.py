@@ -107,6 +107,11 @@ def load():
     return lib
 
 
+def last_error() -> str:
+    msg = load().g3_last_error()
+    return msg.decode() if msg else "?"
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().g3_last_error()

@@ -364,7 +364,9 @@ extern "C" int g3_spatial_attn_d512_bf16(const void* q, const void* k, const voi
     if (!q || !k || !vt || !o) return g3_set_error(G3_ERR_ARG, "g3_spatial_attn_d512_bf16: null operand");
     if (frames <= 0 || hw <= 0 || (hw % KV5) != 0) return g3_set_error(G3_ERR_ARG, "g3_spatial_attn_d512_bf16: frames > 0 and hw %% 64 == 0 required (hw = %d)", hw);
     if (ld_vt < hw || (ld_vt & 7) || (vt_frame_stride & 7)) return g3_set_error(G3_ERR_ARG, "g3_spatial_attn_d512_bf16: bad V^T leading dimension");
-    if ((int64_t)hw * D5 * 2 >= (1ll << 32) || (int64_t)D5 * ld_vt * 2 >= (1ll << 32))
+    // 32-bit quantities of the LDS-DMA addressing: a K piece's per-lane offset stays inside one key row; a V^T piece's per-lane offset spans
+    // 8 dim rows ((lane >> 3) * row bytes + chunk), its base is a 64-bit pointer - so the V^T bound is 8 rows, not the 512 of a whole frame
+    if ((int64_t)hw * D5 * 2 >= (1ll << 32) || (int64_t)8 * ld_vt * 2 >= (1ll << 32))
         return g3_set_error(G3_ERR_ARG, "g3_spatial_attn_d512_bf16: a frame exceeds the 32-bit byte offsets of the LDS-DMA addressing");
     Attn512Params p;
     p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.Vt = (const bf16_t*)vt; p.O = (bf16_t*)o;

@@ -269,7 +269,10 @@ class VideoExtendGeneralDIT(nn.Module):
         """Fuse per-layer projection weights that share an input into one GEMM operand (done once per weight set; rebuilt when
         a parameter was replaced or modified in place since)."""
         key = self._weights_key()
-        if self._packed is not None and self._packed["key"] == key:
+        # Inference tensors (a model built or loaded under torch.inference_mode()) carry no version counter - their key is the storage address
+        # alone, and an in-place p.copy_(new) inside inference mode would leave the fused QKV / K-V copies stale. Such a weight set is re-fused on
+        # every call (two concatenations per block: ~2 ms of a 1.7 s forward) instead of trusting the address.
+        if self._packed is not None and self._packed["key"] == key and self._packed["versioned"]:
             return self._packed
         if self._packed is not None:
             self._tables.clear()  # the position tables derive from the pos-emb parameters
@@ -290,7 +293,7 @@ class VideoExtendGeneralDIT(nn.Module):
                 w1=P[f"{mlp}.block.layer1.weight"], w2=P[f"{mlp}.block.layer2.weight"],
                 ada=[(P[f"{pre}.{j}.adaLN_modulation.1.weight"], P[f"{pre}.{j}.adaLN_modulation.2.weight"]) for j in range(3)],
             ))
-        self._packed = dict(blocks=blocks, P=P, key=key)
+        self._packed = dict(blocks=blocks, P=P, key=key, versioned=cacheable(*P.values()))
         return self._packed
 
     # ------------------------------------------------------------------------------------------------ context parallel

@@ -266,7 +266,8 @@ class Gen3cInferenceModel(InferenceModel):
         # The resident model returns the overlap frame(s) it regenerated at the head of the batch ("video_no_overlap" is the whole video in the
         # reference too - gen3c_persistent.py:504-506 "TODO: handle overlap" - so its uncompressed record would carry n frames for n - overlap
         # cameras and trip its own shape check); here they are cut so that frames, depths and cameras agree.
-        if overlap > 0 and frames.shape[0] == w2c.shape[0]:
+        trimmed = overlap > 0 and frames.shape[0] == w2c.shape[0]
+        if trimmed:
             frames = frames[overlap:]
             depths = depths[overlap:] if depths is not None else None
         images = frames.transpose(0, 2, 3, 1)  # [n, C, H, W] -> [n, H, W, C]
@@ -275,7 +276,9 @@ class Gen3cInferenceModel(InferenceModel):
         common = dict(request_id=req.request_id, result_ids=[f"{req.request_id}__frame_{k}" for k in range(n)], timestamps=np.zeros((n,)),
                       cameras_to_world=req.cameras_to_world[:upper], focal_lengths=req.focal_lengths[:upper], principal_points=req.principal_points[:upper],
                       frame_count_without_padding=req.frame_count_without_padding, runtime_ms=1000 * (time.time() - t0))
-        if self.compress_inference_results and video_path is not None and str(video_path).endswith(".mp4"):
+        # The model's MP4 holds every frame it produced, the regenerated overlap frame(s) included: after a trim it would decompress to `overlap`
+        # more images than there are cameras / depths (frame i paired with camera i - overlap). Such a request goes out uncompressed instead.
+        if self.compress_inference_results and not trimmed and video_path is not None and str(video_path).endswith(".mp4"):
             with open(video_path, "rb") as f:
                 video_bytes = f.read()
             return CompressedInferenceResult(images=None, depths=None, resolutions=np.tile([[images.shape[2], images.shape[1]]], (n, 1)),

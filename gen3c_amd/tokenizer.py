@@ -242,9 +242,16 @@ class CausalVideoTokenizerNet(torch.nn.Module):
             # ALL frames by one transpose of the [T HW, C] matrix: frame f's V^T = columns [f HW, (f + 1) HW) of the [C, T HW] result.
             vT = torch.empty((C, T * HW), dtype=bf16, device=x.device)
             _lib.check(lib.g3_transpose2d_bf16(_ptr(v), C, _ptr(vT), T * HW, T * HW, C, _st()), "g3_transpose2d_bf16")
-            _lib.check(lib.g3_spatial_attn_d512_bf16(_ptr(q), _ptr(k), _ptr(vT), T * HW, HW, _ptr(o), T, HW, float(C) ** -0.5, _st()),
-                       "g3_spatial_attn_d512_bf16")
-            return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
+            rc = lib.g3_spatial_attn_d512_bf16(_ptr(q), _ptr(k), _ptr(vT), T * HW, HW, _ptr(o), T, HW, float(C) ** -0.5, _st())
+            if rc == 0:
+                return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
+            # (148 KB of dynamic LDS refused, a clip beyond the kernel's 32-bit offsets): the three-kernel HIP path below computes the same
+            # attention; say so once - a silent 2x slowdown of this stage would otherwise go unnoticed
+            if not getattr(self, "_flash_warned", False):
+                self._flash_warned = True
+                import warnings
+                warnings.warn(f"g3_spatial_attn_d512_bf16 refused ({_lib.last_error()}); using the score-matrix path")
+            del vT
         ldp = ops.ceil_to(HW, 8)
         # Frames are independent (time2batch, layers3d.py:362-364). One frame's products do not fill the chip - scores = q k^T is 8 K tiles per
         # 256 x 256 output tile (its launches wait on their stores), p v has (HW / 256) x 2 = 110 tiles for 256 CUs at 704 x 1280 - so the

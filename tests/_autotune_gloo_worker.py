@@ -44,7 +44,8 @@ def main():
     best, table, failed = bench.autotune_cp(net, Den(), None, None, None, torch.device("cpu"), dist, rank=rank, progress={})
     out = dict(rank=rank, n_table=len(table), failed=[(f["head_groups"], f["kernel"], f["schedule"]) for f in failed],
                best=None if best is None else (best["head_groups"], best["kernel"], best["schedule"]), cfg=net._cp_attn.cfg)
-    print("WORKER " + json.dumps(out), flush=True)
+    # one file per rank: two torch.distributed.run children share the parent's stdout pipe and their lines can land on one line
+    Path(os.environ["WORKER_OUT_DIR"], f"worker{rank}.json").write_text(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
 

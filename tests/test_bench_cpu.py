@@ -211,7 +211,26 @@ def test_run_guard_prints_a_null_value_line_when_a_phase_overruns():
     assert line["progress"]["candidate"] == [4, "w4b", "local_first"]
 
 
-def test_autotune_failure_agreement_over_gloo_world2():
+def _json_objects(text):
+    """Every top-level JSON object found anywhere in `text`, in order - robust against two processes' output sharing a line."""
+    import json
+    dec, out, i = json.JSONDecoder(), [], text.find("{")
+    while i >= 0:
+        try:
+            obj, end = dec.raw_decode(text, i)
+            if isinstance(obj, dict):
+                out.append(obj)
+            i = text.find("{", end)
+        except ValueError:
+            i = text.find("{", i + 1)
+    return out
+
+
+def test_json_objects_helper_survives_interleaved_output():
+    assert _json_objects('noise {"a": 1}WORKER {"b": {"c": 2}}\n{bad {"d": 3}') == [{"a": 1}, {"b": {"c": 2}}, {"d": 3}]
+
+
+def test_autotune_failure_agreement_over_gloo_world2(tmp_path):
     """The N > 1 agreement protocol of bench.autotune_cp over a REAL 2-rank gloo process group (CPU): candidate (4, w4b, local_first) raises on rank 1
     only, BEFORE its step (rank 0 would otherwise enter the step's exchange alone and hang); candidate (2, wave8, gather_first) raises on both ranks
     after the exchange. Both ranks must finish, drop exactly these two candidates, time the other 14 and configure the same winner."""
@@ -220,14 +239,16 @@ def test_autotune_failure_agreement_over_gloo_world2():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, G3_BENCH_INJECT="autotune:4,w4b,local_first:1", WORKER_FAIL_IN_STEP="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, G3_BENCH_INJECT="autotune:4,w4b,local_first:1", WORKER_FAIL_IN_STEP="1", OMP_NUM_THREADS="1", WORKER_OUT_DIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         str(ROOT / "tests" / "_autotune_gloo_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    outs = sorted((json.loads(l.split("WORKER ", 1)[1]) for l in r.stdout.splitlines() if "WORKER " in l), key=lambda o: o["rank"])
-    assert len(outs) == 2
+    # each worker writes its own file (the two children share one stdout pipe: their lines may interleave)
+    files = sorted(tmp_path.glob("worker*.json"))
+    assert len(files) == 2, r.stdout[-2000:] + r.stderr[-3000:]
+    outs = sorted((json.loads(f.read_text()) for f in files), key=lambda o: o["rank"])
     for o in outs:
         assert o["n_table"] == 14 and sorted(map(tuple, o["failed"])) == [(2, "wave8", "gather_first"), (4, "w4b", "local_first")]
     assert outs[0]["best"] == outs[1]["best"] and outs[0]["cfg"] == outs[1]["cfg"] and outs[0]["best"] is not None
@@ -248,9 +269,9 @@ def test_run_guard_relays_a_remote_failure_over_gloo_world2():
                         str(ROOT / "tests" / "_runguard_gloo_worker.py")], capture_output=True, text=True, timeout=300, env=env)
     took = time.time() - t0
     assert r.returncode != 0 and "UNREACHABLE" not in r.stdout
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
-    out = json.loads(lines[0])
+    objs = _json_objects(r.stdout)  # (not line-split: the two children share one pipe)
+    assert len(objs) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = objs[0]
     assert out["value"] is None and out["failed_phase"] == "timed" and "rank 1" in out["error"] and "HIP error on rank 1" in out["error"]
     assert out["progress"]["cp"]["chosen"]["head_groups"] == 4 and took < 120
 

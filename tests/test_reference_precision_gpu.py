@@ -66,6 +66,13 @@ def test_attention_kernels_next_to_bf16_sdpa():
     ref_prec = rows["oracle TE restatement in bf16 (P -> bf16, fp32 accumulate)"]
     assert rows["HIP one-wave kernel (w4b, default for long self-attention)"] <= SLACK * ref_prec
     assert rows["HIP 8-wave kernel (folded softmax arithmetic)"] <= SLACK * ref_prec
+    # w4b (the default, and the least accurate bf16 variant here: its folded softmax arithmetic trades ~25 % more error for speed) is
+    # pinned next to the vendor-class arithmetic - a later speed tweak cannot silently widen the gap. Today 2.88e-3 vs 2.30e-3 = 1.25x.
+    sdpa_key = "torch.nn.functional.scaled_dot_product_attention in bf16 (this device)"
+    if sdpa_key in rows:
+        ratio = rows["HIP one-wave kernel (w4b, default for long self-attention)"] / rows[sdpa_key]
+        print(f"    w4b / torch bf16 SDPA error ratio = {ratio:.3f} (bound 1.3)")
+        assert ratio <= 1.3
 
 
 def test_full_size_block_hip_vs_reference_precision_oracle():
@@ -134,3 +141,45 @@ def test_fp8_qk_emulation_study():
         print(f"[fp8 QK^T emulation, S={S}, N(0,1) operands, {rows.numel()} sampled rows] rel-L2 vs fp32 attention: e4m3 Q and K {out[S][0]:.3e} | e4m3 Q only {out[S][1]:.3e} "
               f"(bf16 kernels: ~3e-3; tolerance 1e-2)")
     assert out[56320][0] > 1e-2, "e4m3 QK^T met the attention tolerance on this data - revisit the decision not to build it"
+
+
+def test_fp8_pv_emulation_study():
+    """VERDICT r4 #7 / north_star "MFMA bf16/fp8 QK^T.V": the P.V half. Emulates what v_mfma_scale_f32_32x32x64_f8f6f4 would compute with QK^T and the softmax
+    as today (bf16 operands, fp32 scores) and P and V quantised to OCP e4m3: V with one scale per (head) (amax -> 448), P = exp(s - m) in (0, 1] scaled by 256
+    (a power of two: exact, keeps exp(-17) above the e4m3 subnormal floor); products exact, fp32 accumulation; the row sum taken over the QUANTISED P (what
+    the kernel's MFMA would see). Two operand sets per size: N(0,1) (score std 1, near-uniform attention over all keys) and a peaked one (q scaled x4: score
+    std 4, a handful of keys carry the mass). e4m3 = 3 mantissa bits = 2^-4 relative rounding per element (rms 3.6 %); zero-mean V does not average the
+    P errors away, and V's own rounding is another 3.6 % of each term. The assertion documents the outcome (numbers: profiles/r5_parity_measured.txt)."""
+    dev = torch.device("cuda:0")
+    HD = 128
+    if not hasattr(torch, "float8_e4m3fn"):
+        pytest.skip("torch build without float8_e4m3fn")
+    e4 = lambda t: t.to(torch.float8_e4m3fn).float()
+    out = {}
+    for S, H in ((8192, 4), (56320, 1)):
+        for label, qscale in (("N(0,1)", 1.0), ("peaked", 4.0)):
+            g = torch.Generator(device=dev).manual_seed(43 + S)
+            q, k, v = (torch.randn(S, 1, H, HD, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
+            q = (q.float() * qscale).to(torch.bfloat16)
+            rows = torch.randint(0, S, (512,), device=dev, generator=g)
+            sc = torch.einsum("sbhd,tbhd->bhst", q[rows].float(), k.float()) / math.sqrt(HD)
+            e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))  # (0, 1]: what the kernel holds before the deferred normalisation
+            vf = v.float()
+            vamax = vf.abs().amax(dim=(0, 1, 3), keepdim=True)
+            v8 = e4(vf * (448.0 / vamax)) * (vamax / 448.0)
+            e8 = e4(e * 256.0) / 256.0
+            e16 = e.to(torch.bfloat16).float()
+
+            def pv(pp, vv):  # sum over keys / row sum of the same (rounded) weights
+                return torch.einsum("bhst,tbhd->sbhd", pp, vv) / pp.sum(dim=-1).permute(2, 0, 1)[..., None]
+
+            ref = pv(e, vf)
+            r = dict(bf16=_rel(pv(e16, vf), ref), p8=_rel(pv(e8, vf), ref), v8=_rel(pv(e16, v8), ref), p8v8=_rel(pv(e8, v8), ref))
+            out[(S, label)] = r
+            print(f"[fp8 P.V emulation, S={S}, {label} (score std {float(sc.std()):.2f}), 512 sampled rows] rel-L2 vs fp32 P.V: bf16 P (today) {r['bf16']:.3e} | "
+                  f"e4m3 P only {r['p8']:.3e} | e4m3 V only {r['v8']:.3e} | e4m3 P and V {r['p8v8']:.3e}   (tolerance 1e-2)")
+    worst = max(r["p8v8"] for r in out.values())
+    best = min(r["p8v8"] for r in out.values())
+    print(f"[fp8 P.V emulation] e4m3 P and V: best case {best:.3e}, worst case {worst:.3e}")
+    # north_star's fp8 clause is closed on these numbers: an opt-in kernel would need every case <= 1e-2
+    assert worst > 1e-2, "e4m3 P.V met the attention tolerance on every operand set - build it behind G3_ATTN_FP8_PV (VERDICT r4 #7)"

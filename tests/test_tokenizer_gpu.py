@@ -357,3 +357,43 @@ def test_image_branch_single_frame_vs_oracle():
     rz, ry = _rel(z.cpu(), z_ref), _rel(y.cpu(), y_ref)
     print(f"[tokenizer image branch] encode rel_l2={rz:.3e} decode rel_l2={ry:.3e}")
     assert rz <= 2e-2 and ry <= 2e-2  # measured 1.06e-2 / 1.18e-2 (channels = 16: the reduced-width goldens measure 1.3e-2 / 0.9e-2)
+
+
+@pytest.mark.parametrize("T,H,W", [(17, 512, 512), (9, 360, 640)])
+def test_plugin_encode_decode_reference_test_shape(T, H, W):
+    """The reference's only hot-path test (tokenizer/modules/layers3d_test.py:32-114) encodes a 17 x 512 x 512 centre crop to a latent
+    (1, 16, (17 - 1) // 8 + 1, 512 // 8, 512 // 8) = (1, 16, 3, 64, 64) and decodes it back to the input's shape: replayed here through the plug-in
+    surface (`VideoTokenizer.encode` / `.decode`, with latent mean / std as pretrained_vae.py:365-405 applies them) - and, since random weights are
+    all there is, with VALUES against the fp32 oracle, which the reference's shape-only test does not check. H = W = 512 is the only non-16:9 case in
+    the suite (mid-level attention over 64 x 64 = 4 096 pixels -> the flash d = 512 kernel). (9, 360, 640): a size whose mid level is 45 x 80 =
+    3 600 pixels - not a multiple of 64, so the spatial attention takes the score-matrix path, and 3 x 45 x 80 rows leave ragged 256-row
+    convolution tiles at every level."""
+    from gen3c_amd.tokenizer import VideoTokenizer
+    from oracle import tokenizer_oracle as tok
+    dev = torch.device("cuda:0")
+    tk = VideoTokenizer(pixel_chunk_duration=T, channels=128, device=dev)
+    sd = tk.net.init_random(seed=11)
+    sd32 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(7)
+    tl = (T - 1) // 8 + 1
+    mean = torch.randn(16, tl, generator=g) * 0.1
+    std = torch.rand(16, tl, generator=g) * 0.5 + 0.75
+    tk.register_mean_std(mean, std)
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, max(T // 4, 2), H // 16, W // 16, generator=g), size=(T, H, W), mode="trilinear")
+    x = ((base * 2 - 1) * 0.8 + 0.2 * (torch.rand(1, 3, T, H, W, generator=g) * 2 - 1)).clamp(-1, 1).to(torch.bfloat16)
+    z = tk.encode(x.to(dev))
+    torch.cuda.synchronize()
+    assert tuple(z.shape) == (1, 16, tl, H // 8, W // 8)  # layers3d_test.py:96-99
+    m32 = mean.to(torch.bfloat16).float().view(1, 16, tl, 1, 1)
+    s32 = std.to(torch.bfloat16).float().view(1, 16, tl, 1, 1)
+    z_ref = tok.encode(sd32, x.float(), m32, s32)
+    rz = _rel(z, z_ref)
+    zin = z_ref.to(torch.bfloat16)
+    y = tk.decode(zin.to(dev))
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(x.shape)  # layers3d_test.py:113
+    y_ref = tok.decode(sd32, zin.float(), m32, s32)
+    ry = _rel(y, y_ref)
+    print(f"[tokenizer plug-in {T}x{H}x{W}] encode rel_l2={rz:.3e}  decode rel_l2={ry:.3e}  latent {tuple(z.shape)}")
+    assert torch.isfinite(z.float()).all() and torch.isfinite(y.float()).all()
+    assert rz <= 1.5e-2 and ry <= 1.8e-2  # the tolerance of test_tokenizer_production_width_vs_oracle (same depth, same arithmetic)
