@@ -89,6 +89,12 @@ G3_DEVICE void store_tile(const GemmParams& p, f32x16 (&acc)[4][2], int mw, int 
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e];
+                // GELU / gated residual act on the Linear's OUTPUT, which nn.Linear rounds to bf16 (attention.py:94-99, blocks.py:455-471); every GEMM
+                // kernel rounds here since round 5 (gemm_w4e.hpp keeps a finished tile as packed bf16): bitwise equal outputs across the kernels
+                if (EPI == EPI_GELU || EPI == EPI_GATED_RESIDUAL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)f32_to_bf16(v[e]);
+                }
                 if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
@@ -153,6 +159,10 @@ G3_DEVICE void store_tile_lds(const GemmParams& p, f32x16 (&acc)[4][2], int mw, 
             for (int e = 0; e < 4; ++e) {
                 v[e] = lo[e];
                 v[4 + e] = hi[e];
+            }
+            if (EPI == EPI_GELU || EPI == EPI_GATED_RESIDUAL) {  // the Linear's own rounding to bf16 (see store_tile)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)f32_to_bf16(v[e]);
             }
             if (EPI == EPI_GELU) {
 #pragma unroll
@@ -750,6 +760,21 @@ int launch_variant(const GemmParams& p, hipStream_t stream, const char* what) {
 
 #include "gemm_w4.hpp"
 #include "gemm_w4_conv.hpp"
+#include "gemm_w4e.hpp"
+
+static int device_cu_count() {  // cached per device (sizes the persistent grid of gemm_w4e.hpp)
+    static int n_cu[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!n_cu[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu[dev] = cus;
+    }
+    return n_cu[dev];
+}
 
 // CONV on the one-wave-per-SIMD kernel (gemm_w4_conv.hpp): whole 64-channel tiles, >= 2 K tiles, K * 2 bytes inside the zero page,
 // <= 32 spatial taps (bit masks), full-line epilogue, activation span addressable with 32-bit row * lda products
@@ -764,6 +789,12 @@ int launch(const GemmParams& p, hipStream_t stream, const char* what) {
     const bool glds = (p.K % BK) == 0 && !g3_opt_gemm_regstage;
     if constexpr (CONV && (EPI == EPI_NONE || EPI == EPI_BIAS || EPI == EPI_BIAS_RESIDUAL)) {
         if (conv_w4_applies(p)) return launch_w4_conv<EPI>(p, stream, what);
+    }
+    if constexpr (!CONV && (EPI == EPI_NONE || EPI == EPI_GELU || EPI == EPI_GATED_RESIDUAL)) {  // persistent form with the deferred epilogue (gemm_w4e.hpp)
+        if (glds && g3_opt_gemm_pingpong == 3) {
+            const int n_cu = device_cu_count();
+            if (w4e_applies(p, EPI, n_cu)) return launch_w4e<EPI>(p, stream, what, n_cu);
+        }
     }
     if constexpr (!CONV) {  // one wave per SIMD (gemm_w4.hpp): whole 64-wide K tiles, at least two, full-line epilogue
         if (glds && g3_opt_gemm_pingpong == 3 && p.wide_store && p.K >= 2 * BK) return launch_w4<EPI>(p, stream, what);
@@ -821,9 +852,14 @@ extern "C" int g3_gemm_bf16_nt(const void* A, int64_t lda, const void* W, int64_
 // Name of the kernel family g3_gemm_bf16_nt / g3_gemm_qk_norm_rope_bf16 launch for this shape under the options in force (16-byte aligned,
 // 8-element-strided operands assumed - what the DiT passes): for profilers and bench.py's roofline_gemm line, never needed to run the op.
 extern "C" const char* g3_gemm_kernel_name(int M, int N, int K, int epilogue) {
-    (void)M; (void)epilogue;
     const bool glds = (K % BK) == 0 && !g3_opt_gemm_regstage;
     const bool wide = g3_opt_gemm_wide_store && !(N & 7);
+    if (glds && g3_opt_gemm_pingpong == 3 && wide && (epilogue == EPI_NONE || epilogue == EPI_GELU || epilogue == EPI_GATED_RESIDUAL)) {
+        GemmParams p{};
+        p.M = M; p.N = N; p.K = K; p.wide_store = 1; p.gate_rows = 1; p.ldc = p.ldr = N; p.ldg = N;
+        p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+        if (w4e_applies(p, epilogue, device_cu_count())) return "gemm_bf16_nt_w4e_kernel<EPI>";
+    }
     if (glds && g3_opt_gemm_pingpong == 3 && wide && K >= 2 * BK) return "gemm_bf16_nt_w4_kernel<EPI>";
     if (glds && g3_opt_gemm_pingpong >= 2) return "gemm_bf16_nt_pp_kernel<EPI, 2, false>";
     if (glds && g3_opt_gemm_pingpong) return "gemm_bf16_nt_pp_kernel<EPI, 4, false>";

@@ -485,12 +485,12 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_kernel(GemmPar
                     }
                 } else if (EPI == EPI_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast((float)f32_to_bf16(v[e]));  // (the Linear's own rounding first: gemm.hip, store_tile)
                 } else if (EPI != EPI_NONE) {
                     const bf16x8 gv = p.gate_rows == 1 ? gv1 : load_bf16x8(p.gate + (int64_t)(m % p.gate_rows) * p.ldg + n);
                     if (EPI == EPI_GATED_RESIDUAL) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (float)rpre[J][s8][e] + (float)gv[e] * v[e];
+                        for (int e = 0; e < 8; ++e) v[e] = (float)rpre[J][s8][e] + (float)gv[e] * (float)f32_to_bf16(v[e]);
                     } else if (EPI == EPI_BIAS) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)gv[e];

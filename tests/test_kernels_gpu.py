@@ -591,3 +591,66 @@ def test_hip_dot_product_attention_operator_seam():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 2304), (8448, 4096, 4096), (33792, 2048, 2560)])
+@pytest.mark.parametrize("epi,gate_rows", [(0, 1), (1, 1), (2, 1), (2, 2), (2, 4)])
+def test_gemm_deferred_epilogue_kernel(M, N, K, epi, gate_rows):
+    """gemm_bf16_nt_w4e_kernel (csrc/gemm_w4e.hpp, round 5): persistent tile loop, a finished tile's epilogue rides in the next tile's K loop. Against the
+    non-persistent one-wave kernel (same arithmetic, epilogue behind its own K loop): BITWISE equal, whatever a tile's position in its workgroup's list
+    (carried epilogue / bare flush of the last tile); and against fp32. (8192, 4096, 2304): the minimum K (36 K tiles), exactly 2 tiles per workgroup;
+    (8448, 4096, 4096): 528 tiles over 256 workgroups - 2 or 3 tiles each (carry into a carrying tile); (33792, 2048, 2560): 1056 tiles, 4-5 each.
+    gate_rows 2 / 4: the conditional + unconditional branches of the DiT step share one launch (row m uses gate row m % gate_rows)."""
+    from gen3c_amd import _lib, ops
+    dev = _dev()
+    name = _lib.load().g3_gemm_kernel_name(M, N, K, epi).decode()
+    assert name == "gemm_bf16_nt_w4e_kernel<EPI>", name
+    g = torch.Generator(device=dev).manual_seed(M + 3 * N + 7 * K + epi + gate_rows)
+    a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(gate_rows, N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    kw = dict(gate=gate, residual=res) if epi == 2 else {}
+    outs = {}
+    for deferred in (1, 0):
+        ops.set_option("gemm_deferred", deferred)
+        outs[deferred] = ops.gemm_nt(a, w, epilogue=epi, **kw).clone()
+        for _ in range(2):
+            assert torch.equal(outs[deferred], ops.gemm_nt(a, w, epilogue=epi, **kw)), f"deferred={deferred}: not reproducible"
+    ops.set_option("gemm_deferred", 1)
+    torch.cuda.synchronize()
+    diff = (outs[1].float() - outs[0].float()).abs()
+    bad = int((diff > 0).sum())
+    assert bad == 0, f"deferred != plain one-wave kernel: {bad} of {M * N} elements, max |diff| {float(diff.max()):.3e}, first bad row {int((diff > 0).any(dim=1).nonzero()[0])}"
+    rows = torch.arange(0, M, 61, device=dev)  # sampled rows vs fp32 (the full fp32 product of the largest case is 280 MB)
+    ref = a[rows].float() @ w.float().t()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = res[rows].float() + gate[rows % gate_rows].float() * ref
+    _report(f"gemm deferred {M}x{N}x{K} epi{epi} gate_rows{gate_rows}", outs[1][rows], ref)
+    assert _rel_l2(outs[1][rows], ref) < 4e-3
+
+
+def test_gemm_deferred_epilogue_in_place_residual_and_strided_views():
+    """The DiT's gated residual writes x IN PLACE (out aliases the residual) and its operands are column views of wider buffers."""
+    from gen3c_amd import ops
+    dev = _dev()
+    M, N, K = 8192, 4096, 4096
+    g = torch.Generator(device=dev).manual_seed(77)
+    abuf = torch.randn(M, K + 256, device=dev, generator=g).to(torch.bfloat16)
+    a = abuf[:, 128:128 + K]
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(2, N, device=dev, generator=g).to(torch.bfloat16)
+    x0 = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    outs = {}
+    for deferred in (1, 0):
+        ops.set_option("gemm_deferred", deferred)
+        x = x0.clone()
+        ops.gemm_nt(a, w, out=x, epilogue=2, gate=gate, residual=x)
+        outs[deferred] = x
+    ops.set_option("gemm_deferred", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = x0.float() + gate[torch.arange(M, device=dev) % 2].float() * (a.float() @ w.float().t())
+    assert _rel_l2(outs[1], ref) < 4e-3

@@ -34,17 +34,17 @@ def bench_gemm():
         fl = 2.0 * M * N * K
         res_line = []
         outs = {}
-        for rnd in range(2):
-            for variant in (2, 3, "3p"):  # 2 = 8-wave ping-pong, 3 = one wave per SIMD, 3p = the same as a persistent tile loop
+        for rnd in range(3):
+            for variant in (2, 3, "3e"):  # 2 = 8-wave ping-pong, 3 = one wave per SIMD, 3e = the same, persistent with the DEFERRED epilogue (gemm_w4e.hpp, round 5)
                 ops.set_option("gemm_pingpong", 2 if variant == 2 else 3)
-                ops.set_option("gemm_persistent", 1 if variant == "3p" else 0)
+                ops.set_option("gemm_deferred", 1 if variant == "3e" else 0)
                 ms = timeit(lambda: ops.gemm_nt(a, w, out=out, epilogue=epi, **kw), 5)
                 res_line.append((variant, ms, fl / ms / 1e9))
                 if rnd == 0:
                     outs[variant] = out.clone()
         ops.set_option("gemm_pingpong", 3)
-        ops.set_option("gemm_persistent", 0)
-        same = torch.equal(outs[2], outs[3]) and torch.equal(outs[3], outs["3p"])
+        ops.set_option("gemm_deferred", 1)
+        same = torch.equal(outs[2], outs[3]) and torch.equal(outs[3], outs["3e"])
         res_line.append(("bitwise-equal", 0.0 if same else -1.0, 1.0 if same else 0.0))
         if epi == 0:  # vendor-library yardstick for the plain GEMM (hipBLASLt through torch; not part of the product path)
             wt = w.t()
