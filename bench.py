@@ -819,6 +819,18 @@ def main():
         roof_gemm = dict(bound="mfma", kernel=_lib.load().g3_gemm_kernel_name(gm["M"], gm["N"], gm["K"], gm["epilogue"]).decode(), achieved=round(g_fl / (g_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
                          unit="TFLOP/s", frac=round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), launches=len(gemms),
                          total_ms_per_step=round(g_ms / args.steps, 2))
+        # per launch class (epilogue + shape), so that the driver's run shows which class loses: the block's projections / MLP halves
+        lib = _lib.load()
+        epi_name = {0: "none", 1: "gelu", 2: "gated_residual", 3: "bias", 4: "bias_residual"}
+        classes = {}
+        for m, ms in gemms:
+            c = classes.setdefault((m["epilogue"], m["M"], m["N"], m["K"]), [0, 0.0])
+            c[0] += 1
+            c[1] += ms
+        roof_gemm["classes"] = [dict(epilogue=epi_name.get(e, str(e)), M=M, N=N, K=K, launches=n, avg_ms=round(ms / n, 3),
+                                     achieved=round(2.0 * M * N * K * n / (ms * 1e-3) / 1e12, 1), frac=round(2.0 * M * N * K * n / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                     kernel=lib.g3_gemm_kernel_name(M, N, K, e).decode())
+                                for (e, M, N, K), (n, ms) in sorted(classes.items(), key=lambda kv: -kv[1][1]) if ms > 0]
 
     if world > 1:
         cp_info.update(cp_report(net._cp_attn, self_attn, gemms, args.steps, dist.get_world_size() if dist.get_backend() == "nccl" else 0))

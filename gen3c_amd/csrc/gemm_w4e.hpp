@@ -21,6 +21,9 @@
 #include "gemm_w4e_gen.hpp"
 
 constexpr int GW4E_LDS_BYTES = 2 * GW4_STAGE_BYTES + 32768;  // 160 KiB
+#ifndef G3_GW4E_PFD
+#define G3_GW4E_PFD 4  // L2 prefetch distance in K tiles (A/B builds: -DG3_GW4E_PFD=<n>)
+#endif
 constexpr int GW4E_MIN_NK = 36;                               // K tile 0 preamble + 32 period tiles; the gate vectors load at K tile nk - 3 >= 33
 
 template <int EPI>
@@ -98,6 +101,9 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
     E.roff = (uint32_t)(((int64_t)rr * p.ldr + 8 * cc) * 2);
     E.goff = (uint32_t)(((int64_t)(rr % p.gate_rows) * p.ldg + 8 * cc) * 2);
     E.c0 = 0.3275911f * 0.70710678118654752440f;
+    // L2 prefetch (gw4e_*ks2*: one 4-byte load per lane = one 128-byte line per row of the 256-row slice of K tile t + D)
+    E.pfo = (uint32_t)((int64_t)(wave * 64 + lane) * p.lda * 2);
+    E.pfwo = (uint32_t)((int64_t)(wave * 64 + lane) * p.ldw * 2);
 
     int L = blockIdx.x;
     int m0, n0;
@@ -163,8 +169,19 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             }
             return o;
         };
+        // the slices the barrier step prefetches into the L2: K tile t + D of this output tile, or of the next one behind its end
+        auto with_prefetch = [&](GW4EOps o, int t) -> GW4EOps {
+            const int tp = t + G3_GW4E_PFD;
+            const bool in_tile = tp < nk;
+            const int64_t off = (int64_t)(in_tile ? tp : tp - nk) * 128;
+            o.pfb = (in_tile ? t_tile : t_next) + off;
+            o.pfwb = (in_tile ? w_tile : w_next) + off;
+            return o;
+        };
         auto kops = [&](auto sc, auto ksc, int t) -> GW4EOps {  // K tile t with t + 2 < nk
-            return kops_src(sc, ksc, w_tile + (int64_t)(t + 1) * 128, t_tile + (int64_t)(t + 1) * 128, w_tile + (int64_t)(t + 2) * 128);
+            GW4EOps o = kops_src(sc, ksc, w_tile + (int64_t)(t + 1) * 128, t_tile + (int64_t)(t + 1) * 128, w_tile + (int64_t)(t + 2) * 128);
+            if constexpr (decltype(ksc)::value == 2) o = with_prefetch(o, t);
+            return o;
         };
         using K0 = std::integral_constant<int, 0>;
         using K1 = std::integral_constant<int, 1>;
@@ -292,11 +309,11 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             const char* tl = t_tile + (int64_t)(nk - 1) * 128;
             gw4e_ks0(kops_src(S0{}, K0{}, wl, tl, w_next));
             gw4e_ks1(kops_src(S0{}, K1{}, wl, tl, w_next));
-            gw4e_ks2_bar(kops_src(S0{}, K2{}, wl, tl, w_next));
+            gw4e_ks2_bar(with_prefetch(kops_src(S0{}, K2{}, wl, tl, w_next), nk - 2));
             gw4e_ks3(kops_src(S0{}, K3{}, wl, tl, w_next));
             gw4e_ks0(kops_src(S1{}, K0{}, w_next, t_next, w_next + 128));
             gw4e_ks1(kops_src(S1{}, K1{}, w_next, t_next, w_next + 128));
-            gw4e_ks2_bar(kops_src(S1{}, K2{}, w_next, t_next, w_next + 128));
+            gw4e_ks2_bar(with_prefetch(kops_src(S1{}, K2{}, w_next, t_next, w_next + 128), nk - 1));
             gw4e_ks3(kops_src(S1{}, K3{}, w_next, t_next, w_next + 128));
         } else {  // the workgroup's last tile: nothing further to fetch
             gw4e_ks0(kops(S0{}, K0{}, t));

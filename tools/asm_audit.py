@@ -169,6 +169,59 @@ def audit_gemm_w4(asm_text: str):
     return findings
 
 
+def audit_gemm_w4e(asm_text: str):
+    """gemm_w4e.hpp (round 5): from the first fragment read to the end of the kernel the accumulators a0..a255, the fragment buffers v192..v255, the
+    drained tile v64..v191 and the gate vectors v56..v63 belong to the generated asm statements (gemm_w4e_gen.hpp) - the finished tile LIVES in
+    v64..v191 across compiler-generated code (pointer arithmetic, the unit switch), which therefore may not name any of them anywhere in the kernel;
+    no scratch; no scalar memory load behind the first MFMA (the gated-residual statements wait with hand-counted lgkmcnt(N): SMEM returns out of order);
+    every period statement keeps its 16 MFMAs."""
+    findings, cur, funcs = [], None, {}
+    for ln in asm_text.split("\n"):
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4e_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
+        if m:
+            cur = f"gemm_w4e<{m.group(2)}>"
+            funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(ln)
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+    if len(funcs) != 3:
+        findings.append(f"gemm_w4e: expected 3 kernel instances (epilogues 0, 1, 2), found {sorted(funcs)}")
+    for name, v in funcs.items():
+        in_asm, seen_mfma, n_mfma_stmt, n_stmt = False, False, 0, 0
+        for i, l in enumerate(v):
+            t = l.strip()
+            if "ASMSTART" in t:
+                in_asm, n_mfma_stmt = True, 0
+                continue
+            if "ASMEND" in t:
+                in_asm = False
+                if n_mfma_stmt:
+                    n_stmt += 1
+                    if n_mfma_stmt != 16:
+                        findings.append(f"{name}: line {i}: an asm statement with {n_mfma_stmt} MFMAs (a K step has 16)")
+                continue
+            if not t or t[0] in ";.":
+                continue
+            if in_asm:
+                if t.startswith("v_mfma"):
+                    n_mfma_stmt += 1
+                    seen_mfma = True
+                continue
+            if t.startswith("scratch_"):
+                findings.append(f"{name}: line {i}: scratch access `{t}`")
+            if seen_mfma and re.match(r"s_(buffer_)?load_", t):
+                findings.append(f"{name}: line {i}: scalar memory load behind the first MFMA (hand-counted lgkmcnt waits): `{t}`")
+            for m in re.finditer(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b", t):
+                kind = m.group(1) or m.group(4)
+                last = int(m.group(3) or m.group(5))
+                if kind == "a" or last >= 56:
+                    findings.append(f"{name}: line {i}: compiler-generated `{t}` touches an asm-owned register")
+                    break
+        print(f"{name}: {n_stmt} K-step statements audited (asm-owned a0..a255, v56..v255 over the whole kernel, no scratch, no SMEM behind the first MFMA)")
+    return findings
+
+
 def audit_attn_d512(asm_text: str):
     """attention_d512.hip (round 4): all 256 AGPRs hold the O^T accumulators and belong to the asm statements from the zeroing prologue to the
     epilogue's reads - NO compiler-generated instruction of the kernel may name an AGPR (hipcc, left alone, parks the score accumulators in
@@ -239,6 +292,7 @@ def main():
             print(r.stderr)
             sys.exit(2)
         findings += audit_gemm_w4(out2.read_text())
+        findings += audit_gemm_w4e(out2.read_text())
         out3 = Path(td) / "attention_d512.s"
         r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
                             str(ROOT / "gen3c_amd" / "csrc" / "attention_d512.hip"), "-o", str(out3)], capture_output=True, text=True)

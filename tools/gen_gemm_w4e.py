@@ -159,7 +159,7 @@ def check_trans(seq: list[Op]) -> None:
 def fix_waits(seq: list[Op]) -> None:
     """`s_waitcnt lgkmcnt(@tag)`: wait for the LDS read tagged `tag` = number of LDS instructions issued after it, up to the wait."""
     for k, op in enumerate(seq):
-        if op.kind == "wait" and "@" in op.text:
+        if op.kind == "wait" and "lgkmcnt(@" in op.text:
             tag = op.text.split("@")[1].rstrip(")")
             src = max(i for i in range(k) if seq[i].tag == tag)
             n = sum(1 for i in range(src + 1, k) if seq[i].kind == "lds")
@@ -175,12 +175,19 @@ def assemble(ks: int, init: bool, gaps: list[list[Op]], bar: bool, mfmas: bool =
             seq.append(Op(mfma(i, j, cur, init), "mfma"))
         seq.extend(gaps[g])
     if bar:
-        seq.append(Op("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"))
+        seq.append(Op("@GW4E_BARWAIT", "wait"))  # macro: vmcnt(0), or vmcnt(n) with the n L2 prefetch loads of this K step (the youngest VMEM operations) left in flight
         seq.append(Op("s_barrier", "salu"))
     fix_waits(seq)
     check_m0_pairs(seq)
     check_trans(seq)
     return [op.text for op in seq]
+
+
+def prefetch_ops() -> list[Op]:
+    """K step 2 (the barrier step, no LDS-DMA pieces): one plain load per lane that touches the 128-byte line of ONE row of the token (weight) slice of
+    K tile t + D - 64 lanes x 4 waves = the 256 rows of the slice - so that the slice sits in the XCD's L2 when its LDS-DMA pieces ask for it. The
+    data goes to a register nobody reads (v55). Issued last before the barrier, whose wait leaves exactly these loads in flight (macro GW4E_BARWAIT)."""
+    return [Op("@GW4E_PFA", "vmem", pin=9), Op("@GW4E_PFW", "vmem", pin=12)]
 
 
 # ---------------------------------------------------------------------------------------------------------------- epilogue arithmetic of one register
@@ -274,10 +281,12 @@ def operand_lists(texts: list[str], extra_clobber_mem: bool = True):
             if m.group(1) not in names:
                 names.append(m.group(1))
     outs, ins = [], []
+    if any(t == "@GW4E_PFA" for t in texts):
+        names += ["pfo", "pfb", "pfwo", "pfwb"]
     for n in names:
         if n in ("x0", "x1", "t0", "t1", "p0", "p1", "e0", "e1", "g0", "g1", "r", "xt", "xu"):
             outs.append(f'[{n}] "=&v"({n})')
-        elif n in ("adw", "adt", "xr", "yb", "coff", "roff", "xw"):
+        elif n in ("adw", "adt", "xr", "yb", "coff", "roff", "xw", "pfo", "pfwo"):
             ins.append(f'[{n}] "v"(o.{n})')
         elif n.startswith("vo"):
             ins.append(f'[{n}] "v"(o.vo[{n[2:]}])')
@@ -285,7 +294,7 @@ def operand_lists(texts: list[str], extra_clobber_mem: bool = True):
             ins.append(f'[{n}] "s"(o.sb[{n[2:]}])')
         elif n[0] == "m" and n[1:].isdigit():
             ins.append(f'[{n}] "s"(o.m[{n[1:]}])')
-        elif n in ("cb", "rb", "ym", "c0", "rb1", "ym1", "gb0", "gb1", "goff"):
+        elif n in ("cb", "rb", "ym", "c0", "rb1", "ym1", "gb0", "gb1", "goff", "pfb", "pfwb"):
             cons = "v" if n == "goff" else "s"
             ins.append(f'[{n}] "{cons}"(o.{n})')
         else:
@@ -304,7 +313,7 @@ def emit_fn(name: str, texts: list[str], comment: str = "") -> str:
         body.append("    uint32_t " + ", ".join(temps) + ";")
     body.append("    asm volatile(")
     for t in texts:
-        body.append(f'        "{t}\\n\\t"')
+        body.append(f"        {t[1:]}" if t.startswith("@") else f'        "{t}\\n\\t"')
     body.append("        : " + ", ".join(outs))
     body.append("        : " + ", ".join(ins))
     body.append('        : GW4E_OWNED, "memory");')
@@ -325,6 +334,8 @@ def gen_plain() -> str:
     ]
     for name, ks, init, read, np_, bar in variants:
         gaps = base_layout(ks, read, np_)
+        if bar:
+            spread(gaps, prefetch_ops())
         out.append(emit_fn(name, assemble(ks, init, gaps, bar), f"plain K step {ks}" + (" (first of an output tile: C = 0)" if init else "") + (", barrier" if bar else "")))
     # preamble K tile of a carried epilogue: k-step 1 also reads unit 0 back from X (all four chunks)
     gaps = base_layout(1, True, 5)
@@ -342,7 +353,7 @@ def gen_carry(epi: int) -> str:
     for kappa in range(16):
         ks = kappa & 3
         gaps = base_layout(ks, True, (5, 5, 0, 6)[ks])
-        spread(gaps, carry_ops(epi, kappa))
+        spread(gaps, (prefetch_ops() if ks == 2 else []) + carry_ops(epi, kappa))
         out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_k{kappa}", assemble(ks, False, gaps, ks == 2),
                            f"{EPI_NAME[epi]}: period K step kappa = {kappa} (K step {ks}" + (", barrier" if ks == 2 else "") + ")"))
     # flush of one unit without a K loop under it (the workgroup's last output tile): X -> W, residual pieces -> Y, arithmetic, stores
@@ -409,7 +420,25 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 // Instruction streams of gemm_bf16_nt_w4e_kernel (gemm_w4e.hpp): see the generator for the schedule. Included inside gemm.hip's anonymous namespace.
 
 #define GW4E_P_VGPRS @PLIST@
-#define GW4E_OWNED GW4_OWNED, GW4E_P_VGPRS
+#define GW4E_OWNED GW4_OWNED, GW4E_P_VGPRS, "v55"
+
+// L2 prefetch of the operand slices of K tile t + G3_GW4E_PFD (gemm_w4e.hpp). A/B builds: -DG3_AB_GW4E_PF=0 none, 1 token slices only, 2 (default) both
+#ifndef G3_AB_GW4E_PF
+#define G3_AB_GW4E_PF 2
+#endif
+#if G3_AB_GW4E_PF == 0
+#define GW4E_PFA ""
+#define GW4E_PFW ""
+#define GW4E_BARWAIT "s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\t"
+#elif G3_AB_GW4E_PF == 1
+#define GW4E_PFA "global_load_dword v55, %[pfo], %[pfb]\\n\\t"
+#define GW4E_PFW ""
+#define GW4E_BARWAIT "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
+#else
+#define GW4E_PFA "global_load_dword v55, %[pfo], %[pfb]\\n\\t"
+#define GW4E_PFW "global_load_dword v55, %[pfwo], %[pfwb]\\n\\t"
+#define GW4E_BARWAIT "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
+#endif
 
 struct GW4EOps {
     uint32_t adw, adt;                          // fragment read addresses of the NEXT K step
@@ -420,6 +449,7 @@ struct GW4EOps {
     const char* rb; uint32_t ym;                // residual piece: source base, LDS destination
     const char* gb0; const char* gb1;           // gate vectors of the two feature halves
     float c0;                                   // GELU: 0.3275911 / sqrt(2)
+    uint32_t pfo, pfwo; const char* pfb; const char* pfwb;  // L2 prefetch: per-lane row offsets into the token / weight panels, slice bases of K tile t + D
 };
 
 '''
