@@ -422,9 +422,11 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 #define GW4E_P_VGPRS @PLIST@
 #define GW4E_OWNED GW4_OWNED, GW4E_P_VGPRS, "v55"
 
-// L2 prefetch of the operand slices of K tile t + G3_GW4E_PFD (gemm_w4e.hpp). A/B builds: -DG3_AB_GW4E_PF=0 none, 1 token slices only, 2 (default) both
+// L2 prefetch of the operand slices of K tile t + G3_GW4E_PFD (gemm_w4e.hpp): measured SLOWER and off (profiles/r5_gemm_prefetch_ab.txt: token slices only -1..3 %,
+// both -10..15 %: 64 scattered line requests per load on a vector memory path the operand staging already half fills - what round 3 had found for the non-persistent kernel).
+// A/B builds: -DG3_AB_GW4E_PF=0 (default) none, 1 token slices only, 2 both
 #ifndef G3_AB_GW4E_PF
-#define G3_AB_GW4E_PF 2
+#define G3_AB_GW4E_PF 0
 #endif
 #if G3_AB_GW4E_PF == 0
 #define GW4E_PFA ""
