@@ -327,7 +327,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
         }
 
         // ---- drain (the only dead time between two K loops): accumulators -> P
-        gw4e_drain();
+        if (!(G3_AB_GW4E_ABLATE & 8)) gw4e_drain();  // (bit 8: timing ablation)
         m0e = m0;
         n0e = n0;
         if (!has_next) {

@@ -48,7 +48,8 @@ def test_every_period_statement_has_its_16_mfmas_and_balanced_gaps():
     fns = re.findall(r"G3_DEVICE void (gw4e_(?:none|gelu|gated)_k\d+)\(const GW4EOps& o\) \{(.*?)\n\}", text, re.S)
     assert len(fns) == 48
     for name, body in fns:
-        lines = [l.strip().strip('"').replace("\\n\\t", "") for l in body.split("\n") if l.strip().startswith('"')]
+        lines = [re.sub(r'^GW4E_AB_\w\("', "", l.strip()).strip('")').replace("\\n\\t", "") for l in body.split("\n")
+                 if l.strip().startswith('"') or l.strip().startswith("GW4E_")]
         idx = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
         assert len(idx) == 16, name
         gaps = [idx[k + 1] - idx[k] - 1 for k in range(15)] + [len(lines) - idx[-1] - 1]

@@ -55,8 +55,9 @@ GELU_E = f(-0.5) * f(1.44269504088896340736)
 class Op:
     """One instruction of a statement. kind: valu / trans / lds / vmem / salu / wait. pin: gap index it must sit in (None: spread)."""
 
-    def __init__(self, text: str, kind: str = "valu", pin: int | None = None, tag: str = "", last: bool = False):
+    def __init__(self, text: str, kind: str = "valu", pin: int | None = None, tag: str = "", last: bool = False, ab: str = ""):
         self.text, self.kind, self.pin, self.tag, self.last = text, kind, pin, tag, last  # last: pinned op that goes BEHIND the spread ops of its gap
+        self.ab = ab  # timing-ablation class (macro GW4E_AB_<ab>): "M" epilogue arithmetic, "S" stores, "L" epilogue LDS traffic + residual pieces
 
 
 def frag(buf: int, fi: int) -> str:
@@ -180,7 +181,11 @@ def assemble(ks: int, init: bool, gaps: list[list[Op]], bar: bool, mfmas: bool =
     fix_waits(seq)
     check_m0_pairs(seq)
     check_trans(seq)
-    return [op.text for op in seq]
+    return [ab_text(op) for op in seq]
+
+
+def ab_text(op: Op) -> str:
+    return f"#{op.ab}#{op.text}" if op.ab else op.text
 
 
 def prefetch_ops() -> list[Op]:
@@ -196,6 +201,13 @@ def w_reg(kappa: int) -> str:
 
 
 def math_ops(epi: int, kappa: int, flush: bool = False) -> list[Op]:
+    ops = _math_ops(epi, kappa, flush)
+    for op in ops:
+        op.ab = "L" if op.kind == "lds" else ("" if op.kind == "wait" else "M")
+    return ops
+
+
+def _math_ops(epi: int, kappa: int, flush: bool = False) -> list[Op]:
     w = w_reg(kappa)
     if epi == EPI_NONE:
         return []
@@ -245,22 +257,22 @@ TEMPS = {EPI_NONE: [], EPI_GELU: ["x0", "x1", "t0", "t1", "p0", "p1", "e0", "e1"
 
 def x_read(ch: int) -> Op:
     b = P0 + 4 * ch
-    return Op(f"ds_read_b128 v[{b}:{b + 3}], %[xr] offset:{1024 * ch}", "lds")
+    return Op(f"ds_read_b128 v[{b}:{b + 3}], %[xr] offset:{1024 * ch}", "lds", ab="L")
 
 
 def store_chunk(ch: int, pin: int | None = 15) -> Op:
     b = P0 + 4 * ch
-    return Op(f"global_store_dwordx4 %[coff], v[{b}:{b + 3}], %[cb]", "vmem", pin=pin, last=pin is not None)
+    return Op(f"global_store_dwordx4 %[coff], v[{b}:{b + 3}], %[cb]", "vmem", pin=pin, last=pin is not None, ab="S")
 
 
 def resid_piece(pin_m0: int | None, pin_ld: int | None) -> list[Op]:
-    return [Op("s_mov_b32 m0, %[ym]", "salu", pin=pin_m0, tag="m0:y"), Op("global_load_lds_dwordx4 %[roff], %[rb]", "vmem", pin=pin_ld, tag="ld:y")]
+    return [Op("s_mov_b32 m0, %[ym]", "salu", pin=pin_m0, tag="m0:y", ab="L"), Op("global_load_lds_dwordx4 %[roff], %[rb]", "vmem", pin=pin_ld, tag="ld:y", ab="L")]
 
 
 def carry_ops(epi: int, kappa: int) -> list[Op]:
     ops: list[Op] = []
     if kappa in (1, 5, 9, 13):
-        ops.append(Op(x_read({1: 3, 5: 0, 9: 1, 13: 2}[kappa]).text, "lds", pin=8))  # behind the fragment reads (gaps 0..7)
+        ops.append(Op(x_read({1: 3, 5: 0, 9: 1, 13: 2}[kappa]).text, "lds", pin=8, ab="L"))  # behind the fragment reads (gaps 0..7)
     if epi == EPI_GATED and (kappa & 3) == 3:
         # k-step 3 carries six operand pieces: M0 / load pairs at gaps (0,1) (3,4) (5,6) (8,9) (11,12) (13,14); the residual piece sits between the
         # first pair's load and the second pair's s_mov (m0 at the end of gap 1, load in gap 2): the earliest slot, three K steps ahead of the barrier
@@ -313,7 +325,13 @@ def emit_fn(name: str, texts: list[str], comment: str = "") -> str:
         body.append("    uint32_t " + ", ".join(temps) + ";")
     body.append("    asm volatile(")
     for t in texts:
-        body.append(f"        {t[1:]}" if t.startswith("@") else f'        "{t}\\n\\t"')
+        if t.startswith("@"):
+            body.append(f"        {t[1:]}")
+        elif t.startswith("#"):
+            _, cls, txt = t.split("#", 2)
+            body.append(f'        GW4E_AB_{cls}("{txt}\\n\\t")')
+        else:
+            body.append(f'        "{t}\\n\\t"')
     body.append("        : " + ", ".join(outs))
     body.append("        : " + ", ".join(ins))
     body.append('        : GW4E_OWNED, "memory");')
@@ -339,7 +357,7 @@ def gen_plain() -> str:
         out.append(emit_fn(name, assemble(ks, init, gaps, bar), f"plain K step {ks}" + (" (first of an output tile: C = 0)" if init else "") + (", barrier" if bar else "")))
     # preamble K tile of a carried epilogue: k-step 1 also reads unit 0 back from X (all four chunks)
     gaps = base_layout(1, True, 5)
-    spread(gaps, [Op(x_read(ch).text, "lds", pin=8 + 2 * ch) for ch in range(4)])
+    spread(gaps, [Op(x_read(ch).text, "lds", pin=8 + 2 * ch, ab="L") for ch in range(4)])
     out.append(emit_fn("gw4e_ks1_pre", assemble(1, False, gaps, False), "preamble K tile, K step 1: + transposing reads of unit 0 (chunks 0..3) into W"))
     # gated residual: the finished tile's two gate vectors (feature halves) into v[56:59] / v[60:63], behind K step 3 of K tile nk - 3
     gaps = base_layout(3, True, 6)
@@ -359,7 +377,7 @@ def gen_carry(epi: int) -> str:
     # flush of one unit without a K loop under it (the workgroup's last output tile): X -> W, residual pieces -> Y, arithmetic, stores
     # (the residual pieces of the unit are issued from C++ by gw4e_resid_piece before this statement, whose closing wait covers them)
     seq: list[Op] = [Op("s_waitcnt lgkmcnt(0)", "wait")] + [x_read(ch) for ch in range(4)] + [Op("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
-    out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_flush_load", [op.text for op in seq], f"{EPI_NAME[epi]}: flush, unit registers back from X (and the residual pieces landed)"))
+    out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_flush_load", [ab_text(op) for op in seq], f"{EPI_NAME[epi]}: flush, unit registers back from X (and the residual pieces landed)"))
     for ch in range(4):
         seq = []
         for kappa in range(4 * ch, 4 * ch + 4):
@@ -368,7 +386,7 @@ def gen_carry(epi: int) -> str:
         seq.append(store_chunk(ch, pin=None))
         fix_waits(seq)
         check_trans(seq)
-        out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_flush_c{ch}", [op.text for op in seq], f"{EPI_NAME[epi]}: flush, arithmetic + store of chunk {ch}"))
+        out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_flush_c{ch}", [ab_text(op) for op in seq], f"{EPI_NAME[epi]}: flush, arithmetic + store of chunk {ch}"))
     return "\n".join(out)
 
 
@@ -399,13 +417,13 @@ def gen_misc() -> str:
                 k = 4 * il + q
                 r = P0 + 16 * u + 8 * il + 2 * q
                 if k == 0:
-                    texts.append(f"ds_write_b64 %[xw], v[{r}:{r + 1}]")
+                    texts.append(f"#L#ds_write_b64 %[xw], v[{r}:{r + 1}]")
                 else:
                     xt = "%[xt]" if k & 1 else "%[xu]"  # two address temporaries in turn: a write's address register is not rewritten straight behind it
-                    texts += [f"v_xor_b32 {xt}, {16 * k}, %[xw]", f"ds_write_b64 {xt}, v[{r}:{r + 1}]"]
+                    texts += [f"#L#v_xor_b32 {xt}, {16 * k}, %[xw]", f"#L#ds_write_b64 {xt}, v[{r}:{r + 1}]"]
         out.append(emit_fn(f"gw4e_xwrite_{u}", texts, f"unit {u} (token block {u >> 1}, feature half {u & 1}): registers v[{P0 + 16 * u}:{P0 + 16 * u + 15}] -> LDS slice X"))
     # one residual LDS-DMA piece outside a K step (behind the drain; flush)
-    out.append(emit_fn("gw4e_resid_piece", ["s_mov_b32 m0, %[ym]", "s_nop 0", "global_load_lds_dwordx4 %[roff], %[rb]"], "one residual piece -> Y slot (outside a K step)"))
+    out.append(emit_fn("gw4e_resid_piece", ["#L#s_mov_b32 m0, %[ym]", "s_nop 0", "#L#global_load_lds_dwordx4 %[roff], %[rb]"], "one residual piece -> Y slot (outside a K step)"))
     # gate vectors change halves between two units
     texts = [f"v_swap_b32 v{G0 + k}, v{G0 + 4 + k}" for k in range(4)]
     body = ["// the other feature half's gate vector becomes the current one (v[56:59])", "G3_DEVICE void gw4e_gate_swap() {", "    asm volatile("]
@@ -421,6 +439,27 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 
 #define GW4E_P_VGPRS @PLIST@
 #define GW4E_OWNED GW4_OWNED, GW4E_P_VGPRS, "v55"
+
+// timing ablations of the deferred epilogue (tools/gemm_ablate_w4e.py; results are garbage): -DG3_AB_GW4E_ABLATE=<bits>  1: no epilogue arithmetic, 2: no stores,
+// 4: no epilogue LDS traffic / residual pieces, 8: no drain (gemm_w4e.hpp)
+#ifndef G3_AB_GW4E_ABLATE
+#define G3_AB_GW4E_ABLATE 0
+#endif
+#if G3_AB_GW4E_ABLATE & 1
+#define GW4E_AB_M(x) ""
+#else
+#define GW4E_AB_M(x) x
+#endif
+#if G3_AB_GW4E_ABLATE & 2
+#define GW4E_AB_S(x) ""
+#else
+#define GW4E_AB_S(x) x
+#endif
+#if G3_AB_GW4E_ABLATE & 4
+#define GW4E_AB_L(x) ""
+#else
+#define GW4E_AB_L(x) x
+#endif
 
 // L2 prefetch of the operand slices of K tile t + G3_GW4E_PFD (gemm_w4e.hpp): measured SLOWER and off (profiles/r5_gemm_prefetch_ab.txt: token slices only -1..3 %,
 // both -10..15 %: 64 scattered line requests per load on a vector memory path the operand staging already half fills - what round 3 had found for the non-persistent kernel).
