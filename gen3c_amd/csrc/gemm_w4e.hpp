@@ -13,7 +13,7 @@
 //   * LDS: the two 64 KiB operand stages + per wave a 4 KiB transpose slice X and a 4 KiB residual slice Y (LDS-DMA destination) = all 160 KiB;
 //   * the workgroup's LAST tile has no K loop to ride in: the same instruction sequences run bare (gw4e_*_flush_*), so a tile's values do not depend
 //     on its position in the workgroup's tile list.
-// Applies to (host: w4e_applies): M, N multiples of 256, K of 128, >= 36 K tiles (33 carry the epilogue), epilogues NONE / GELU / GATED_RESIDUAL with
+// Applies to (host: w4e_applies): M, N multiples of 256, K of 128, >= 38 K tiles (34 carry the epilogue), epilogues NONE / GELU / GATED_RESIDUAL with
 // gate_rows in {1, 2, 4}, full-line alignment. Everything else runs on gemm_bf16_nt_w4_kernel. Off: g3_set_option("gemm_deferred", 0).
 // Arithmetic: bf16(acc) first, then the epilogue in fp32 with the operation order of store_tile_lds (which rounds the same way since round 5): bitwise
 // equal outputs across all GEMM kernels (tests/test_kernels_gpu.py).
@@ -24,7 +24,7 @@ constexpr int GW4E_LDS_BYTES = 2 * GW4_STAGE_BYTES + 32768;  // 160 KiB
 #ifndef G3_GW4E_PFD
 #define G3_GW4E_PFD 4  // L2 prefetch distance in K tiles (A/B builds: -DG3_GW4E_PFD=<n>)
 #endif
-constexpr int GW4E_MIN_NK = 36;                               // K tile 0 preamble + 32 period tiles; the gate vectors load at K tile nk - 3 >= 33
+constexpr int GW4E_MIN_NK = 38;                               // K tile 0 preamble + 32 period tiles + tiles 33 (last store), 34; the gate vectors load at K tile nk - 3 >= 35
 
 template <int EPI>
 __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmParams p) {
@@ -176,6 +176,10 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             const int64_t off = (int64_t)(in_tile ? tp : tp - nk) * 128;
             o.pfb = (in_tile ? t_tile : t_next) + off;
             o.pfwb = (in_tile ? w_tile : w_next) + off;
+            // leader (A/B build G3_AB_GW4E_PF = 3): of the workgroups an XCD runs side by side (4 token tiles x 8 feature tiles of the XCD-aware
+            // order) the one with feature tile % 8 == 0 fetches the token slice
+            const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((((in_tile ? n0 : n0n) / BN) & 7) == 0 ? -1 : 0);
+            o.pfxa = ((uint64_t)la << 32) | la;
             return o;
         };
         auto kops = [&](auto sc, auto ksc, int t) -> GW4EOps {  // K tile t with t + 2 < nk
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             // ---- 8 periods of 4 K tiles: the arithmetic and stores of unit u, the transposition of unit u + 1
             for (int u = 0; u < 8; ++u) {
                 char* cb = unit_c(u);
+                char* cb_prev3 = unit_c(u > 0 ? u - 1 : 0) + 3 * c_chunk;
                 const char* rb_u = (EPI == EPI_GATED_RESIDUAL) ? unit_r(u) : nullptr;
                 const char* rb_n = (EPI == EPI_GATED_RESIDUAL) ? unit_r(min(u + 1, 7)) : nullptr;
                 if (EPI == EPI_GATED_RESIDUAL && u > 0) gw4e_gate_swap();
@@ -236,8 +241,10 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
                     auto step = [&](auto ksc) {
                         constexpr int KS = decltype(ksc)::value, KAPPA = 4 * TAU + KS;
                         GW4EOps o = kops(SC{}, ksc, tt);
-                        if constexpr (KS == 3) {
-                            o.cb = cb + (int64_t)TAU * c_chunk;  // store of chunk TAU
+                        if constexpr (KS == 2) {
+                            // the barrier step stores the chunk finished one K tile earlier: chunk 3 of the PREVIOUS unit at kappa = 2 (unit 0 has
+                            // none: the statement without a store), chunks 0, 1, 2 of this unit after
+                            o.cb = TAU == 0 ? cb_prev3 : cb + (int64_t)(TAU - 1) * c_chunk;
                             if constexpr (EPI == EPI_GATED_RESIDUAL) {  // residual pieces (u,2) (u,3) (u+1,0) (u+1,1) -> Y slot = chunk
                                 constexpr int SLOT = (TAU + 2) & 3;
                                 o.rb = (TAU < 2 ? rb_u : rb_n) + (int64_t)SLOT * r_chunk;
@@ -245,21 +252,21 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
                             }
                         }
                         if constexpr (EPI == EPI_NONE) {
-                            if constexpr (KAPPA == 0) gw4e_none_k0(o); else if constexpr (KAPPA == 1) gw4e_none_k1(o); else if constexpr (KAPPA == 2) gw4e_none_k2(o);
+                            if constexpr (KAPPA == 0) gw4e_none_k0(o); else if constexpr (KAPPA == 1) gw4e_none_k1(o); else if constexpr (KAPPA == 2) { if (u == 0) gw4e_none_k2f(o); else gw4e_none_k2(o); }
                             else if constexpr (KAPPA == 3) gw4e_none_k3(o); else if constexpr (KAPPA == 4) gw4e_none_k4(o); else if constexpr (KAPPA == 5) gw4e_none_k5(o);
                             else if constexpr (KAPPA == 6) gw4e_none_k6(o); else if constexpr (KAPPA == 7) gw4e_none_k7(o); else if constexpr (KAPPA == 8) gw4e_none_k8(o);
                             else if constexpr (KAPPA == 9) gw4e_none_k9(o); else if constexpr (KAPPA == 10) gw4e_none_k10(o); else if constexpr (KAPPA == 11) gw4e_none_k11(o);
                             else if constexpr (KAPPA == 12) gw4e_none_k12(o); else if constexpr (KAPPA == 13) gw4e_none_k13(o); else if constexpr (KAPPA == 14) gw4e_none_k14(o);
                             else gw4e_none_k15(o);
                         } else if constexpr (EPI == EPI_GELU) {
-                            if constexpr (KAPPA == 0) gw4e_gelu_k0(o); else if constexpr (KAPPA == 1) gw4e_gelu_k1(o); else if constexpr (KAPPA == 2) gw4e_gelu_k2(o);
+                            if constexpr (KAPPA == 0) gw4e_gelu_k0(o); else if constexpr (KAPPA == 1) gw4e_gelu_k1(o); else if constexpr (KAPPA == 2) { if (u == 0) gw4e_gelu_k2f(o); else gw4e_gelu_k2(o); }
                             else if constexpr (KAPPA == 3) gw4e_gelu_k3(o); else if constexpr (KAPPA == 4) gw4e_gelu_k4(o); else if constexpr (KAPPA == 5) gw4e_gelu_k5(o);
                             else if constexpr (KAPPA == 6) gw4e_gelu_k6(o); else if constexpr (KAPPA == 7) gw4e_gelu_k7(o); else if constexpr (KAPPA == 8) gw4e_gelu_k8(o);
                             else if constexpr (KAPPA == 9) gw4e_gelu_k9(o); else if constexpr (KAPPA == 10) gw4e_gelu_k10(o); else if constexpr (KAPPA == 11) gw4e_gelu_k11(o);
                             else if constexpr (KAPPA == 12) gw4e_gelu_k12(o); else if constexpr (KAPPA == 13) gw4e_gelu_k13(o); else if constexpr (KAPPA == 14) gw4e_gelu_k14(o);
                             else gw4e_gelu_k15(o);
                         } else {
-                            if constexpr (KAPPA == 0) gw4e_gated_k0(o); else if constexpr (KAPPA == 1) gw4e_gated_k1(o); else if constexpr (KAPPA == 2) gw4e_gated_k2(o);
+                            if constexpr (KAPPA == 0) gw4e_gated_k0(o); else if constexpr (KAPPA == 1) gw4e_gated_k1(o); else if constexpr (KAPPA == 2) { if (u == 0) gw4e_gated_k2f(o); else gw4e_gated_k2(o); }
                             else if constexpr (KAPPA == 3) gw4e_gated_k3(o); else if constexpr (KAPPA == 4) gw4e_gated_k4(o); else if constexpr (KAPPA == 5) gw4e_gated_k5(o);
                             else if constexpr (KAPPA == 6) gw4e_gated_k6(o); else if constexpr (KAPPA == 7) gw4e_gated_k7(o); else if constexpr (KAPPA == 8) gw4e_gated_k8(o);
                             else if constexpr (KAPPA == 9) gw4e_gated_k9(o); else if constexpr (KAPPA == 10) gw4e_gated_k10(o); else if constexpr (KAPPA == 11) gw4e_gated_k11(o);
@@ -270,13 +277,23 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
                     step(K0{});
                     step(K1{});
                     step(K2{});
-                    // behind the barrier of the period's first K tile: X is free (unit u's chunk 3 was read in kappa = 1) -> unit u + 1 goes in
+                    step(K3{});
+                    // behind the period's first K tile: X is free (unit u's chunk 3 was read in kappa = 3) -> unit u + 1 goes in
                     if constexpr (TAU == 0)
                         if (u < 7) xwrite(u + 1);
-                    step(K3{});
                 });
             }
-            t = 33;
+            // ---- K tile 33: its barrier step stores the last unit's chunk 3; K tile 34 brings the plain loop back to an odd tile index
+            {
+                gw4e_ks0(kops(S1{}, K0{}, 33));
+                gw4e_ks1(kops(S1{}, K1{}, 33));
+                GW4EOps o = kops(S1{}, K2{}, 33);
+                o.cb = unit_c(7) + 3 * c_chunk;
+                gw4e_ks2_bar_store3(o);
+                gw4e_ks3(kops(S1{}, K3{}, 33));
+                plain_tile(S0{}, 34);
+            }
+            t = 35;
         } else {
             gw4e_ks0_init(kops(S0{}, K0{}, 0));
             gw4e_ks1(kops(S0{}, K1{}, 0));

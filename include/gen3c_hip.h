@@ -37,8 +37,9 @@ extern "C" {
 
 const char* g3_last_error(void);
 int g3_abi_version(void);
-/* runtime switches for A/B measurements: "gemm_regstage", "gemm_rowmajor_tiles", "gemm_unpinned" (0/1),
- * "attn_variant" (1 = non-pipelined, 2 = software-pipelined, 3 = LDS-DMA + pinned interleave, the default). */
+/* runtime switches for A/B measurements: "gemm_regstage", "gemm_rowmajor_tiles", "gemm_unpinned" (0/1), "gemm_pingpong" (3 = one wave per SIMD, the
+ * default), "gemm_deferred" (1 = the persistent block GEMM with the deferred epilogue where it applies, the default; 0 = epilogue behind every K loop),
+ * "gemm_persistent", "conv_w4", "attn_variant" (0 = automatic), "attn_xcd_heads", "splat_tiled", "render_overlap", "tok_tattn_px". Outputs do not depend on them. */
 int g3_set_option(const char* name /*host*/, int value);
 int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name /*host*/, int arch_name_len);
 

@@ -593,12 +593,12 @@ def test_hip_dot_product_attention_operator_seam():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 4096, 2304), (8448, 4096, 4096), (33792, 2048, 2560)])
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 2432), (8448, 4096, 4096), (33792, 2048, 2560)])
 @pytest.mark.parametrize("epi,gate_rows", [(0, 1), (1, 1), (2, 1), (2, 2), (2, 4)])
 def test_gemm_deferred_epilogue_kernel(M, N, K, epi, gate_rows):
     """gemm_bf16_nt_w4e_kernel (csrc/gemm_w4e.hpp, round 5): persistent tile loop, a finished tile's epilogue rides in the next tile's K loop. Against the
     non-persistent one-wave kernel (same arithmetic, epilogue behind its own K loop): BITWISE equal, whatever a tile's position in its workgroup's list
-    (carried epilogue / bare flush of the last tile); and against fp32. (8192, 4096, 2304): the minimum K (36 K tiles), exactly 2 tiles per workgroup;
+    (carried epilogue / bare flush of the last tile); and against fp32. (8192, 4096, 2432): the minimum K (38 K tiles), exactly 2 tiles per workgroup;
     (8448, 4096, 4096): 528 tiles over 256 workgroups - 2 or 3 tiles each (carry into a carrying tile); (33792, 2048, 2560): 1056 tiles, 4-5 each.
     gate_rows 2 / 4: the conditional + unconditional branches of the DiT step share one launch (row m uses gate row m % gate_rows)."""
     from gen3c_amd import _lib, ops

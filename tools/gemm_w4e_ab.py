@@ -1,15 +1,18 @@
 """A/B of build-time variants of the deferred-epilogue GEMM (csrc/gemm_w4e.hpp) at the benchmark shapes, interleaved in one process on one box.
 Build HERE before gpurun:  python tools/gemm_w4e_ab.py --build      (copies of the library with -DG3_AB_GW4E_PF=0 / 1, -DG3_GW4E_PFD=8)
 GPU box:                   python tools/gemm_w4e_ab.py
-Variants: product (L2 prefetch of both operand slices, 4 K tiles ahead), pf0 (no prefetch), pf1 (token slices only), pfd8 (8 K tiles ahead),
+Variants (G3_W4E_AB_VARIANTS="name=flags;..."): product (no prefetch), pf1 (token slices by every workgroup), pf2 (token + weight slices), pf3 / pf4 (leaders only),
 and the product library with gemm_deferred = 0 (the non-persistent one-wave kernel)."""
 import ctypes as C
+import os
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-VARIANTS = [("pf0", ("-DG3_AB_GW4E_PF=0",)), ("pf1", ("-DG3_AB_GW4E_PF=1",)), ("pfd8", ("-DG3_GW4E_PFD=8",))]
+# pf3 / pf4: only the LEADER of the workgroups that share a slice prefetches it (token slices / token + weight slices)
+VARIANTS = [(v.split("=")[0], tuple(v.split("=", 1)[1].split())) for v in (os.environ.get("G3_W4E_AB_VARIANTS") or
+            "pf1=-DG3_AB_GW4E_PF=1;pf2=-DG3_AB_GW4E_PF=2;pf3=-DG3_AB_GW4E_PF=3;pf4=-DG3_AB_GW4E_PF=4").split(";")]
 
 if "--build" in sys.argv:
     from gen3c_amd import build

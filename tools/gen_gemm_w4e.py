@@ -16,10 +16,11 @@ XOR row & 7) into W = v[64:79] in row layout: lane (rr = lane >> 3, c = lane & 7
 W[4 ch : 4 ch + 3] - one 16-byte store per chunk, 8 lanes = one 128-byte line.
 
 Period of 16 K steps (kappa = 0..15) per unit u, K tiles 1 + 4 u .. 4 + 4 u of the NEXT output tile (K tile 0 = preamble):
-   every kappa        the epilogue arithmetic of register W[kappa]  (none / GELU / residual + gate * x with the residual word read just in time from LDS slice Y)
-   kappa = 4 c + 3    store chunk c (last gap)                       kappa = 3, 7, 11, 15   residual LDS-DMA piece (u,2) (u,3) (u+1,0) (u+1,1) -> Y slot
-   kappa = 5, 9, 13   transposing read of unit u + 1's chunks 0, 1, 2 into W (their registers are done); kappa = 1: chunk 3 of unit u
-   between kappa = 2 and 3 (C++ side): unit u + 1's registers -> X  (gw4e_xwrite_<u>: the only statement that names a unit's registers)
+   every kappa          the epilogue arithmetic of register W[kappa]  (none / GELU / residual + gate * x with the residual word read just in time from LDS slice Y)
+   kappa = 2, 6, 10, 14 (the BARRIER step: no operand LDS-DMA in it) store of chunk 3 of unit u - 1 / chunks 0, 1, 2 of unit u, and the residual LDS-DMA piece
+                        (u,2) (u,3) (u+1,0) (u+1,1) -> Y slot; both are the last VMEM operations in front of the barrier, whose vmcnt(n) leaves them in flight
+   kappa = 3            transposing read of unit u's chunk 3 into W[12:15] (stored one step earlier); kappa = 7, 11, 15: chunks 0, 1, 2 of unit u + 1
+   between kappa = 3 and 4 (C++ side): unit u + 1's registers -> X  (gw4e_xwrite_<u>: the only statement that names a unit's registers)
 
 usage: python tools/gen_gemm_w4e.py [--check]     (--check: exit 1 if the committed header differs from what this script generates)"""
 from __future__ import annotations
@@ -167,7 +168,9 @@ def fix_waits(seq: list[Op]) -> None:
             op.text = f"s_waitcnt lgkmcnt({n})"
 
 
-def assemble(ks: int, init: bool, gaps: list[list[Op]], bar: bool, mfmas: bool = True) -> list[str]:
+def assemble(ks: int, init: bool, gaps: list[list[Op]], bar: bool, mfmas: bool = True, trailing: int = 0) -> list[str]:
+    """trailing: number of VMEM operations at the END of a barrier step (store, residual piece) that the barrier's wait leaves in flight - vmcnt retires in
+    order, so `vmcnt(n)` still certifies every LDS-DMA piece issued before them."""
     cur = ks & 1
     seq: list[Op] = [Op("s_waitcnt lgkmcnt(0)", "wait")]
     order = [(i, j) for j in range(4) for i in range(4)]
@@ -176,7 +179,7 @@ def assemble(ks: int, init: bool, gaps: list[list[Op]], bar: bool, mfmas: bool =
             seq.append(Op(mfma(i, j, cur, init), "mfma"))
         seq.extend(gaps[g])
     if bar:
-        seq.append(Op("@GW4E_BARWAIT", "wait"))  # macro: vmcnt(0), or vmcnt(n) with the n L2 prefetch loads of this K step (the youngest VMEM operations) left in flight
+        seq.append(Op(f"@GW4E_BARWAIT_{trailing}", "wait"))  # macro: vmcnt(trailing [+ 1 with the leader's L2 prefetch load behind them])
         seq.append(Op("s_barrier", "salu"))
     fix_waits(seq)
     check_m0_pairs(seq)
@@ -192,7 +195,7 @@ def prefetch_ops() -> list[Op]:
     """K step 2 (the barrier step, no LDS-DMA pieces): one plain load per lane that touches the 128-byte line of ONE row of the token (weight) slice of
     K tile t + D - 64 lanes x 4 waves = the 256 rows of the slice - so that the slice sits in the XCD's L2 when its LDS-DMA pieces ask for it. The
     data goes to a register nobody reads (v55). Issued last before the barrier, whose wait leaves exactly these loads in flight (macro GW4E_BARWAIT)."""
-    return [Op("@GW4E_PFA", "vmem", pin=9), Op("@GW4E_PFW", "vmem", pin=12)]
+    return [Op("@GW4E_PFA", "vmem", pin=15, last=True)]
 
 
 # ---------------------------------------------------------------------------------------------------------------- epilogue arithmetic of one register
@@ -269,18 +272,24 @@ def resid_piece(pin_m0: int | None, pin_ld: int | None) -> list[Op]:
     return [Op("s_mov_b32 m0, %[ym]", "salu", pin=pin_m0, tag="m0:y", ab="L"), Op("global_load_lds_dwordx4 %[roff], %[rb]", "vmem", pin=pin_ld, tag="ld:y", ab="L")]
 
 
-def carry_ops(epi: int, kappa: int) -> list[Op]:
+def carry_ops(epi: int, kappa: int, store: bool = True) -> tuple[list[Op], int]:
+    """Epilogue micro-ops of period K step kappa and the number of trailing VMEM operations its barrier leaves in flight (K step 2 only).
+    Stores and residual pieces ride in the BARRIER step (it carries no operand LDS-DMA), as the last VMEM operations in front of the barrier: the
+    timing ablation priced a store behind K step 3's six pieces at 3.5-5 % of a launch (profiles/r5_gemm_w4e_ablation.txt)."""
     ops: list[Op] = []
-    if kappa in (1, 5, 9, 13):
-        ops.append(Op(x_read({1: 3, 5: 0, 9: 1, 13: 2}[kappa]).text, "lds", pin=8, ab="L"))  # behind the fragment reads (gaps 0..7)
-    if epi == EPI_GATED and (kappa & 3) == 3:
-        # k-step 3 carries six operand pieces: M0 / load pairs at gaps (0,1) (3,4) (5,6) (8,9) (11,12) (13,14); the residual piece sits between the
-        # first pair's load and the second pair's s_mov (m0 at the end of gap 1, load in gap 2): the earliest slot, three K steps ahead of the barrier
-        ops += resid_piece(1, 2)
+    ks = kappa & 3
+    trailing = 0
+    if ks == 3:  # transposing read into the registers whose chunk was stored one step earlier: chunk 3 of THIS unit at kappa = 3, chunks 0..2 of the next
+        ops.append(Op(x_read({3: 3, 7: 0, 11: 1, 15: 2}[kappa]).text, "lds", pin=10, ab="L"))
+    if ks == 2:
+        if epi == EPI_GATED:
+            ops += resid_piece(10, 11)
+            trailing += 1
     ops += math_ops(epi, kappa)
-    if (kappa & 3) == 3:
-        ops.append(store_chunk(kappa >> 2))
-    return ops
+    if ks == 2 and store:
+        ops.append(store_chunk({2: 3, 6: 0, 10: 1, 14: 2}[kappa], pin=14))
+        trailing += 1
+    return ops, trailing
 
 
 # ---------------------------------------------------------------------------------------------------------------- C++ emission
@@ -294,7 +303,7 @@ def operand_lists(texts: list[str], extra_clobber_mem: bool = True):
                 names.append(m.group(1))
     outs, ins = [], []
     if any(t == "@GW4E_PFA" for t in texts):
-        names += ["pfo", "pfb", "pfwo", "pfwb"]
+        names += ["pfo", "pfb", "pfxa"]
     for n in names:
         if n in ("x0", "x1", "t0", "t1", "p0", "p1", "e0", "e1", "g0", "g1", "r", "xt", "xu"):
             outs.append(f'[{n}] "=&v"({n})')
@@ -306,7 +315,7 @@ def operand_lists(texts: list[str], extra_clobber_mem: bool = True):
             ins.append(f'[{n}] "s"(o.sb[{n[2:]}])')
         elif n[0] == "m" and n[1:].isdigit():
             ins.append(f'[{n}] "s"(o.m[{n[1:]}])')
-        elif n in ("cb", "rb", "ym", "c0", "rb1", "ym1", "gb0", "gb1", "goff", "pfb", "pfwb"):
+        elif n in ("cb", "rb", "ym", "c0", "rb1", "ym1", "gb0", "gb1", "goff", "pfb", "pfwb", "pfxa", "pfxw"):
             cons = "v" if n == "goff" else "s"
             ins.append(f'[{n}] "{cons}"(o.{n})')
         else:
@@ -355,6 +364,10 @@ def gen_plain() -> str:
         if bar:
             spread(gaps, prefetch_ops())
         out.append(emit_fn(name, assemble(ks, init, gaps, bar), f"plain K step {ks}" + (" (first of an output tile: C = 0)" if init else "") + (", barrier" if bar else "")))
+    # K tile 33 (the first behind the eight periods): its barrier step stores the last unit's chunk 3
+    gaps = base_layout(2, True, 0)
+    spread(gaps, [store_chunk(3, pin=14)] + prefetch_ops())
+    out.append(emit_fn("gw4e_ks2_bar_store3", assemble(2, False, gaps, True, trailing=1), "plain K step 2 + store of W[12:15] (chunk 3 of the last unit), barrier"))
     # preamble K tile of a carried epilogue: k-step 1 also reads unit 0 back from X (all four chunks)
     gaps = base_layout(1, True, 5)
     spread(gaps, [Op(x_read(ch).text, "lds", pin=8 + 2 * ch, ab="L") for ch in range(4)])
@@ -371,9 +384,15 @@ def gen_carry(epi: int) -> str:
     for kappa in range(16):
         ks = kappa & 3
         gaps = base_layout(ks, True, (5, 5, 0, 6)[ks])
-        spread(gaps, (prefetch_ops() if ks == 2 else []) + carry_ops(epi, kappa))
-        out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_k{kappa}", assemble(ks, False, gaps, ks == 2),
+        ops, trailing = carry_ops(epi, kappa)
+        spread(gaps, ops + (prefetch_ops() if ks == 2 else []))
+        out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_k{kappa}", assemble(ks, False, gaps, ks == 2, trailing=trailing),
                            f"{EPI_NAME[epi]}: period K step kappa = {kappa} (K step {ks}" + (", barrier" if ks == 2 else "") + ")"))
+    # kappa = 2 of the FIRST period: there is no previous unit whose chunk 3 could be stored (and W[12:15] still holds unit 0's raw chunk 3)
+    gaps = base_layout(2, True, 0)
+    ops, trailing = carry_ops(epi, 2, store=False)
+    spread(gaps, ops + prefetch_ops())
+    out.append(emit_fn(f"gw4e_{EPI_NAME[epi]}_k2f", assemble(2, False, gaps, True, trailing=trailing), f"{EPI_NAME[epi]}: period K step kappa = 2 of unit 0 (no store), barrier"))
     # flush of one unit without a K loop under it (the workgroup's last output tile): X -> W, residual pieces -> Y, arithmetic, stores
     # (the residual pieces of the unit are issued from C++ by gw4e_resid_piece before this statement, whose closing wait covers them)
     seq: list[Op] = [Op("s_waitcnt lgkmcnt(0)", "wait")] + [x_read(ch) for ch in range(4)] + [Op("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
@@ -463,22 +482,20 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 
 // L2 prefetch of the operand slices of K tile t + G3_GW4E_PFD (gemm_w4e.hpp): measured SLOWER and off (profiles/r5_gemm_prefetch_ab.txt: token slices only -1..3 %,
 // both -10..15 %: 64 scattered line requests per load on a vector memory path the operand staging already half fills - what round 3 had found for the non-persistent kernel).
-// A/B builds: -DG3_AB_GW4E_PF=0 (default) none, 1 token slices only, 2 both
+// A/B builds: -DG3_AB_GW4E_PF=0 (default) none, 3 token slices by the leader workgroup only (+2 % on MLP-down, +-0 elsewhere; relies on an EXEC = 0 load still counting in vmcnt)
 #ifndef G3_AB_GW4E_PF
 #define G3_AB_GW4E_PF 0
 #endif
 #if G3_AB_GW4E_PF == 0
 #define GW4E_PFA ""
-#define GW4E_PFW ""
-#define GW4E_BARWAIT "s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\t"
-#elif G3_AB_GW4E_PF == 1
-#define GW4E_PFA "global_load_dword v55, %[pfo], %[pfb]\\n\\t"
-#define GW4E_PFW ""
-#define GW4E_BARWAIT "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
-#else
-#define GW4E_PFA "global_load_dword v55, %[pfo], %[pfb]\\n\\t"
-#define GW4E_PFW "global_load_dword v55, %[pfwo], %[pfwb]\\n\\t"
-#define GW4E_BARWAIT "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
+#define GW4E_BARWAIT_0 "s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\t"
+#define GW4E_BARWAIT_1 "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
+#define GW4E_BARWAIT_2 "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
+#else  // 3: only the LEADER among the workgroups that share a token slice prefetches it (EXEC = 0 for the others: no request leaves the CU)
+#define GW4E_PFA "s_mov_b64 exec, %[pfxa]\\n\\tglobal_load_dword v55, %[pfo], %[pfb]\\n\\ts_mov_b64 exec, -1\\n\\t"
+#define GW4E_BARWAIT_0 "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
+#define GW4E_BARWAIT_1 "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
+#define GW4E_BARWAIT_2 "s_waitcnt vmcnt(3) lgkmcnt(0)\\n\\t"
 #endif
 
 struct GW4EOps {
@@ -491,6 +508,7 @@ struct GW4EOps {
     const char* gb0; const char* gb1;           // gate vectors of the two feature halves
     float c0;                                   // GELU: 0.3275911 / sqrt(2)
     uint32_t pfo, pfwo; const char* pfb; const char* pfwb;  // L2 prefetch: per-lane row offsets into the token / weight panels, slice bases of K tile t + D
+    uint64_t pfxa, pfxw;                        // EXEC masks of the prefetch loads (all ones for the leader workgroup of a slice, else 0)
 };
 
 '''
