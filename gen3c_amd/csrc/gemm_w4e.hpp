@@ -26,7 +26,10 @@ constexpr int GW4E_LDS_BYTES = 2 * GW4_STAGE_BYTES + 32768;  // 160 KiB
 #endif
 constexpr int GW4E_MIN_NK = 38;                               // K tile 0 preamble + 32 period tiles + tiles 33 (last store), 34; the gate vectors load at K tile nk - 3 >= 35
 
-template <int EPI>
+// TF (token pieces first): the order in which a K tile's 16 LDS-DMA pieces are requested. false (gemm_w4.hpp's order): weight rows 0..5 two K tiles ahead (K step 3),
+// weight rows 6, 7 + token rows one tile ahead (K steps 0, 1); true: the same with the operands' roles swapped - the token panel gets the longer lead. The token
+// operand of MLP-down is a 3.7 GB stream from HBM (K = 16 384), its weights come from the L2 / Infinity Cache: host heuristic in launch_w4e (N <= 4096).
+template <int EPI, bool TF>
 __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmParams p) {
     static_assert(EPI == EPI_NONE || EPI == EPI_GELU || EPI == EPI_GATED_RESIDUAL, "gemm_bf16_nt_w4e_kernel: epilogue class without a deferred form");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [stage 2][W tile | T tile][X 4 waves x 4 KiB][Y 4 waves x 4 KiB]
@@ -78,6 +81,10 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     if (lds0 & 127u) __builtin_trap();
     const uint32_t m0_w = lds0 + (uint32_t)wave * 8192u, m0_t = lds0 + GW4_T_OFF + (uint32_t)wave * 8192u;
+    // "first" / "second" operand of the piece order (see TF)
+    const uint32_t (&vo_f)[8] = TF ? vo_t : vo_w;
+    const uint32_t (&vo_s)[8] = TF ? vo_w : vo_t;
+    const uint32_t m0_f = TF ? m0_t : m0_w, m0_s = TF ? m0_w : m0_t;
     uint32_t adw[2][4], adt[2][4];
     {
         const uint32_t c0 = (uint32_t)((g ^ ((l31 >> 1) & 7)) << 4);
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
     const char* w_tile = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
     const char* t_tile = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
 
-    // ---- prologue: K tile 0 complete (stage 0), weight rows 0..5 of K tile 1 (stage 1), first fragments
+    // ---- prologue: K tile 0 complete (stage 0), the first operand's rows 0..5 of K tile 1 (stage 1), first fragments
 #pragma unroll
     for (int q = 0; q < 8; ++q)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + vo_w[q]),
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
                                          (__attribute__((address_space(3))) void*)(uintptr_t)(m0_t + 1024u * q), 16, 0, 0);
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_tile + 128 + vo_w[q]),
-                                         (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((TF ? t_tile : w_tile) + 128 + vo_f[q]),
+                                         (__attribute__((address_space(3))) void*)(uintptr_t)(m0_f + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();
     asm volatile("ds_read_b128 v[192:195], %0\n\tds_read_b128 v[196:199], %0 offset:4096\n\tds_read_b128 v[200:203], %0 offset:8192\n\t"
@@ -142,9 +149,13 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
         if (has_next) tile_origin(Lnext, m0n, n0n);
         const char* w_next = reinterpret_cast<const char*>(p.W + (int64_t)n0n * p.ldw);
         const char* t_next = reinterpret_cast<const char*>(p.A + (int64_t)m0n * p.lda);
+        const char* f_tile = TF ? t_tile : w_tile;
+        const char* s_tile = TF ? w_tile : t_tile;
+        const char* f_next = TF ? t_next : w_next;
+        const char* s_next = TF ? w_next : t_next;
         // (the sources of K tiles t + 1 / t + 2 are given explicitly: inside an output tile they are plain strides of its panels - no per-step select;
         //  only the last two K tiles of an output tile reach into the next one)
-        auto kops_src = [&](auto sc, auto ksc, const char* w1, const char* t1, const char* w2) -> GW4EOps {
+        auto kops_src = [&](auto sc, auto ksc, const char* f1, const char* s1, const char* f2) -> GW4EOps {
             constexpr int S = decltype(sc)::value, KS = decltype(ksc)::value;
             constexpr uint32_t SO = S * GW4_STAGE_BYTES, SN = (S ^ 1) * GW4_STAGE_BYTES;
             GW4EOps o = E;
@@ -157,15 +168,15 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             }
             if constexpr (KS == 0) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) o.m[q] = m0_w + SN + 1024u * (6 + q), o.vo[q] = vo_w[6 + q], o.sb[q] = w1;
+                for (int q = 0; q < 2; ++q) o.m[q] = m0_f + SN + 1024u * (6 + q), o.vo[q] = vo_f[6 + q], o.sb[q] = f1;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) o.m[2 + q] = m0_t + SN + 1024u * q, o.vo[2 + q] = vo_t[q], o.sb[2 + q] = t1;
+                for (int q = 0; q < 3; ++q) o.m[2 + q] = m0_s + SN + 1024u * q, o.vo[2 + q] = vo_s[q], o.sb[2 + q] = s1;
             } else if constexpr (KS == 1) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) o.m[q] = m0_t + SN + 1024u * (3 + q), o.vo[q] = vo_t[3 + q], o.sb[q] = t1;
+                for (int q = 0; q < 5; ++q) o.m[q] = m0_s + SN + 1024u * (3 + q), o.vo[q] = vo_s[3 + q], o.sb[q] = s1;
             } else if constexpr (KS == 3) {
 #pragma unroll
-                for (int q = 0; q < 6; ++q) o.m[q] = m0_w + SO + 1024u * q, o.vo[q] = vo_w[q], o.sb[q] = w2;
+                for (int q = 0; q < 6; ++q) o.m[q] = m0_f + SO + 1024u * q, o.vo[q] = vo_f[q], o.sb[q] = f2;
             }
             return o;
         };
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             return o;
         };
         auto kops = [&](auto sc, auto ksc, int t) -> GW4EOps {  // K tile t with t + 2 < nk
-            GW4EOps o = kops_src(sc, ksc, w_tile + (int64_t)(t + 1) * 128, t_tile + (int64_t)(t + 1) * 128, w_tile + (int64_t)(t + 2) * 128);
+            GW4EOps o = kops_src(sc, ksc, f_tile + (int64_t)(t + 1) * 128, s_tile + (int64_t)(t + 1) * 128, f_tile + (int64_t)(t + 2) * 128);
             if constexpr (decltype(ksc)::value == 2) o = with_prefetch(o, t);
             return o;
         };
@@ -322,16 +333,16 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
             ++t;
         }
         if (has_next) {  // K tiles nk - 2, nk - 1 fetch the next output tile's K tiles 0, 1
-            const char* wl = w_tile + (int64_t)(nk - 1) * 128;
-            const char* tl = t_tile + (int64_t)(nk - 1) * 128;
-            gw4e_ks0(kops_src(S0{}, K0{}, wl, tl, w_next));
-            gw4e_ks1(kops_src(S0{}, K1{}, wl, tl, w_next));
-            gw4e_ks2_bar(with_prefetch(kops_src(S0{}, K2{}, wl, tl, w_next), nk - 2));
-            gw4e_ks3(kops_src(S0{}, K3{}, wl, tl, w_next));
-            gw4e_ks0(kops_src(S1{}, K0{}, w_next, t_next, w_next + 128));
-            gw4e_ks1(kops_src(S1{}, K1{}, w_next, t_next, w_next + 128));
-            gw4e_ks2_bar(with_prefetch(kops_src(S1{}, K2{}, w_next, t_next, w_next + 128), nk - 1));
-            gw4e_ks3(kops_src(S1{}, K3{}, w_next, t_next, w_next + 128));
+            const char* fl = f_tile + (int64_t)(nk - 1) * 128;
+            const char* sl = s_tile + (int64_t)(nk - 1) * 128;
+            gw4e_ks0(kops_src(S0{}, K0{}, fl, sl, f_next));
+            gw4e_ks1(kops_src(S0{}, K1{}, fl, sl, f_next));
+            gw4e_ks2_bar(with_prefetch(kops_src(S0{}, K2{}, fl, sl, f_next), nk - 2));
+            gw4e_ks3(kops_src(S0{}, K3{}, fl, sl, f_next));
+            gw4e_ks0(kops_src(S1{}, K0{}, f_next, s_next, f_next + 128));
+            gw4e_ks1(kops_src(S1{}, K1{}, f_next, s_next, f_next + 128));
+            gw4e_ks2_bar(with_prefetch(kops_src(S1{}, K2{}, f_next, s_next, f_next + 128), nk - 1));
+            gw4e_ks3(kops_src(S1{}, K3{}, f_next, s_next, f_next + 128));
         } else {  // the workgroup's last tile: nothing further to fetch
             gw4e_ks0(kops(S0{}, K0{}, t));
             gw4e_ks1(kops(S0{}, K1{}, t));
@@ -416,8 +427,8 @@ static bool w4e_applies(const GemmParams& p, int epi, int n_cu) {
     return true;
 }
 
-template <int EPI>
-int launch_w4e(const GemmParams& p, hipStream_t stream, const char* what, int n_cu) {
+template <int EPI, bool TF>
+int launch_w4e_tf(const GemmParams& p, hipStream_t stream, const char* what, int n_cu) {
     static bool attr_set[64] = {};
     static std::mutex attr_mu;
     int dev_id = 0;
@@ -425,12 +436,21 @@ int launch_w4e(const GemmParams& p, hipStream_t stream, const char* what, int n_
     {
         std::lock_guard<std::mutex> lock(attr_mu);
         if (!attr_set[dev_id]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4e_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GW4E_LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_w4e_kernel<EPI, TF>), hipFuncAttributeMaxDynamicSharedMemorySize, GW4E_LDS_BYTES);
             if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "gemm: hipFuncSetAttribute(w4e): %s", hipGetErrorString(e));
             attr_set[dev_id] = true;
         }
     }
     const int grid = (n_cu / 8) * 8;
-    hipLaunchKernelGGL((gemm_bf16_nt_w4e_kernel<EPI>), dim3(grid), dim3(GW4_THREADS), GW4E_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_w4e_kernel<EPI, TF>), dim3(grid), dim3(GW4_THREADS), GW4E_LDS_BYTES, stream, p);
     return g3_check_launch(what);
+}
+
+// piece order by shape: g3_set_option("gemm_tokens_first", 0 / 1 / 2): never / always / (default) where few feature tiles share a token panel (N <= 4096: its
+// rows are fetched from HBM by the first of at most 16 workgroups and everybody waits for them) - measured (profiles/r5_gemm_tokens_first_ab.txt): out-projection +1 %,
+// MLP-down +1.5 %; QKV (N = 12 288) -3.5 %, MLP-up (N = 16 384) -1 % -> those keep the weights-first order
+template <int EPI>
+int launch_w4e(const GemmParams& p, hipStream_t stream, const char* what, int n_cu) {
+    const bool tf = g3_opt_gemm_tokens_first == 1 || (g3_opt_gemm_tokens_first == 2 && p.N <= 4096);
+    return tf ? launch_w4e_tf<EPI, true>(p, stream, what, n_cu) : launch_w4e_tf<EPI, false>(p, stream, what, n_cu);
 }

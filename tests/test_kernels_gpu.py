@@ -618,6 +618,10 @@ def test_gemm_deferred_epilogue_kernel(M, N, K, epi, gate_rows):
         for _ in range(2):
             assert torch.equal(outs[deferred], ops.gemm_nt(a, w, epilogue=epi, **kw)), f"deferred={deferred}: not reproducible"
     ops.set_option("gemm_deferred", 1)
+    for tf in (0, 1):  # both LDS-DMA piece orders of the deferred kernel (weight rows / token rows two K tiles ahead; default: by shape)
+        ops.set_option("gemm_tokens_first", tf)
+        assert torch.equal(outs[1], ops.gemm_nt(a, w, epilogue=epi, **kw)), f"gemm_tokens_first={tf} changes the result"
+    ops.set_option("gemm_tokens_first", 2)
     torch.cuda.synchronize()
     diff = (outs[1].float() - outs[0].float()).abs()
     bad = int((diff > 0).sum())

@@ -177,16 +177,16 @@ def audit_gemm_w4e(asm_text: str):
     every period statement keeps its 16 MFMAs."""
     findings, cur, funcs = [], None, {}
     for ln in asm_text.split("\n"):
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4e_kernelILi(\d+)EEEvNS_10GemmParamsE):", ln)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm_bf16_nt_w4e_kernelILi(\d+)ELb([01])EEEvNS_10GemmParamsE):", ln)
         if m:
-            cur = f"gemm_w4e<{m.group(2)}>"
+            cur = f"gemm_w4e<{m.group(2)}, {'tokens' if m.group(3) == '1' else 'weights'} first>"
             funcs[cur] = []
         elif cur is not None:
             funcs[cur].append(ln)
             if ln.startswith(".Lfunc_end"):
                 cur = None
-    if len(funcs) != 3:
-        findings.append(f"gemm_w4e: expected 3 kernel instances (epilogues 0, 1, 2), found {sorted(funcs)}")
+    if len(funcs) != 6:
+        findings.append(f"gemm_w4e: expected 6 kernel instances (epilogues 0, 1, 2 x piece order), found {sorted(funcs)}")
     for name, v in funcs.items():
         in_asm, seen_mfma, n_mfma_stmt, n_stmt = False, False, 0, 0
         for i, l in enumerate(v):

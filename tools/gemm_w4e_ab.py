@@ -11,8 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 # pf3 / pf4: only the LEADER of the workgroups that share a slice prefetches it (token slices / token + weight slices)
-VARIANTS = [(v.split("=")[0], tuple(v.split("=", 1)[1].split())) for v in (os.environ.get("G3_W4E_AB_VARIANTS") or
-            "pf1=-DG3_AB_GW4E_PF=1;pf2=-DG3_AB_GW4E_PF=2;pf3=-DG3_AB_GW4E_PF=3;pf4=-DG3_AB_GW4E_PF=4").split(";")]
+VARIANTS = [(v.split("=")[0], tuple(v.split("=", 1)[1].split())) for v in (os.environ.get("G3_W4E_AB_VARIANTS") or "pf3=-DG3_AB_GW4E_PF=3").split(";") if v]
 
 if "--build" in sys.argv:
     from gen3c_amd import build
@@ -24,7 +23,7 @@ import torch  # noqa: E402
 from gen3c_amd import _lib  # noqa: E402
 from tools.microbench import timeit  # noqa: E402
 
-libs = [("plain-w4", _lib.load(), 0), ("product", _lib.load(), 1)]
+libs = [("plain-w4", _lib.load(), 0, 0), ("product", _lib.load(), 1, 0), ("tokens-first", _lib.load(), 1, 1)]  # (label, library, gemm_deferred, gemm_tokens_first)
 for suffix, _ in VARIANTS:
     f = ROOT / "gen3c_amd" / "lib" / f"libgen3c_hip_{suffix}.so"
     if not f.exists():
@@ -32,7 +31,7 @@ for suffix, _ in VARIANTS:
     lib = C.CDLL(str(f))
     for name, argtypes in _lib.SIGNATURES.items():
         getattr(lib, name).argtypes = argtypes
-    libs.append((suffix, lib, 1))
+    libs.append((suffix, lib, 1, 0))
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 B = 2  # the benchmark's launches carry both CFG branches: M = 2 x 56 320
@@ -45,9 +44,10 @@ for (nm, M, N, K, epi) in [("qkv", 56320 * B, 12288, 4096, 0), ("out", 56320 * B
     fl = 2.0 * M * N * K
     for rnd in range(3):
         line = []
-        for (label, lib, deferred) in libs:
+        for (label, lib, deferred, tf) in libs:
             lib.g3_set_option(b"gemm_pingpong", 3)
             lib.g3_set_option(b"gemm_deferred", deferred)
+            lib.g3_set_option(b"gemm_tokens_first", tf)
             out = outs.setdefault(label, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
             def run():
                 rc = lib.g3_gemm_bf16_nt(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, epi, gate.data_ptr() if epi == 2 else None, B, N,
@@ -61,3 +61,4 @@ for (nm, M, N, K, epi) in [("qkv", 56320 * B, 12288, 4096, 0), ("out", 56320 * B
     print(f"   outputs of all variants bitwise equal: {same}", flush=True)
     del a, w, gate, res, outs
 _lib.load().g3_set_option(b"gemm_deferred", 1)
+_lib.load().g3_set_option(b"gemm_tokens_first", 0)
