@@ -91,6 +91,39 @@ __global__ __launch_bounds__(256) void warp_project_kernel(const float* __restri
     }
 }
 
+// z-only pre-pass of the FUSED form (round 5): the splat recomputes a pixel's projection itself (warp_splat_windows_kernel<true>), but its depth weight
+// exp(50 log1p(z) / max) needs the maximum of log1p(z) over the whole GROUP of items before any pixel is weighted. This pass reads the points (12 bytes per
+// pixel), evaluates z with the operation order of warp_project_kernel (the same float, bit for bit) and leaves the group maximum; nothing else is written.
+__global__ __launch_bounds__(256) void warp_zmax_kernel(const float* __restrict__ points, const float* __restrict__ w2c, const float* __restrict__ Kmat,
+                                                        unsigned* __restrict__ group_max, int n, int h, int w, int group_size, const int* __restrict__ src) {
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const int sitem = src ? src[item] : item;
+    const float* W = w2c + item * 16;
+    const float* K = Kmat + item * 9;
+    float zmax = 0.f;
+    const int stride = gridDim.x * 256;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += stride) {
+        const int64_t so = (int64_t)sitem * hw + pix;
+        const float x = points[so * 3 + 0], y = points[so * 3 + 1], zz = points[so * 3 + 2];
+        float cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
+        const float z = (K[6] * cam[0] + K[7] * cam[1]) + K[8] * cam[2];
+        zmax = fmaxf(zmax, fmaxf(z, 0.f));
+    }
+    float local_max = log1pf(zmax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+    __shared__ float wave_max[4];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = local_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        atomicMax(group_max + item / group_size, __float_as_uint(m));
+    }
+}
+
 // small vector helpers of the mesh-occlusion test (also used by the resolve pass when it applies the occlusion itself)
 struct V3 { float x, y, z; };
 G3_DEVICE V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -306,12 +339,17 @@ G3_DEVICE int from_lane_plus32(int v) {   // lanes 0..31 receive the value of la
 }
 G3_DEVICE float from_lane_minus32(float v) { return __int_as_float(from_lane_minus32(__float_as_int(v))); }
 
+// FUSED (round 5, g3_render_items_f32): the projection of warp_project_kernel is evaluated HERE from the points (same operation order: z, flow and validity are
+// the same floats) - the z / flow / validity planes are neither written nor read back (32 bytes per pixel and item less on the memory side).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
                                                                  const float* __restrict__ flow, const float* __restrict__ maskz,
                                                                  const unsigned* __restrict__ group_max, float* __restrict__ accum,
                                                                  float* __restrict__ windows, int* __restrict__ origins, int n, int h, int w,
                                                                  int group_size, int tiles_x, const int* __restrict__ src_idx = nullptr,
-                                                                 unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0) {
+                                                                 unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0,
+                                                                 const float* __restrict__ points = nullptr, const float* __restrict__ w2c = nullptr,
+                                                                 const float* __restrict__ Kmat = nullptr, const float* __restrict__ mask1 = nullptr) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
     __shared__ int org_w[4][4];  // per-wave minima of the north-west / maxima of the south-east destination corners: window origin and extent
     __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
@@ -334,10 +372,18 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         inb[k] = py < h && px < w;
         const int pix = inb[k] ? py * w + px : 0;
         const int64_t o = (int64_t)item * hw + pix;
-        mk[k] = maskz[o];
-        zin[k] = zbuf[o];
-        flx[k] = flow[((int64_t)item * 2 + 0) * hw + pix];
-        fly[k] = flow[((int64_t)item * 2 + 1) * hw + pix];
+        if constexpr (FUSED) {  // (raw operands now, the projection below - behind the window's zero fill)
+            const int64_t so = (int64_t)sitem * hw + pix;
+            flx[k] = points[so * 3 + 0];
+            fly[k] = points[so * 3 + 1];
+            zin[k] = points[so * 3 + 2];
+            mk[k] = mask1 ? mask1[so] : 1.0f;
+        } else {
+            mk[k] = maskz[o];
+            zin[k] = zbuf[o];
+            flx[k] = flow[((int64_t)item * 2 + 0) * hw + pix];
+            fly[k] = flow[((int64_t)item * 2 + 1) * hw + pix];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[k][c] = image[((int64_t)sitem * 3 + c) * hw + pix];
     }
@@ -346,6 +392,30 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         for (int i = threadIdx.x; i < WIN * WIN * ACC_C / 4; i += 256) wz[i] = zero4;
         for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
+    }
+    if constexpr (FUSED) {
+        // warp_project_kernel's arithmetic, operation for operation (the library is built with -ffp-contract=off): world point -> camera -> pixel,
+        // flow = u - px (splat_geom adds px back: the rounding of the reference's flow12 + grid), validity = mask * (z > 0)
+        const float* W = w2c + item * 16;
+        const float* K = Kmat + item * 9;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
+            const float x = flx[k], y = fly[k], zz = zin[k];
+            float cam[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
+            float pr[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pr[i] = (K[i * 3 + 0] * cam[0] + K[i * 3 + 1] * cam[1]) + K[i * 3 + 2] * cam[2];
+            const float z = pr[2];
+            const float u = pr[0] / (z + 1e-7f);
+            const float v = pr[1] / (z + 1e-7f);
+            flx[k] = u - (float)px;
+            fly[k] = v - (float)py;
+            zin[k] = z;
+            mk[k] = mk[k] * ((z > 0.f) ? 1.0f : 0.0f);
+        }
     }
     // Accumulate into the window. A thread owns 4 consecutive rows of one column; a wave 8 rows x 32 columns (lanes 0..31: rows 8 v .. 8 v + 3,
     // lanes 32..63: rows 8 v + 4 .. 8 v + 7). LDS float atomics are what bounds this kernel (see above: ~6 LDS cycles per LANE), so contributions
@@ -1141,8 +1211,9 @@ extern "C" int g3_warp_splat_resolve_f32(const float* image, const float* z, con
     float* windows = (float*)workspace;
     int* origins = (int*)((char*)workspace + (size_t)n * ntiles * WIN * WIN * ACC_C * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image, z, flow, maskz, (const unsigned*)group_max, accum,
-                       windows, origins, n, h, w, group_size, tiles_x);
+    hipLaunchKernelGGL(warp_splat_windows_kernel<false>, dim3(ntiles, n), dim3(256), 0, s, image, z, flow, maskz, (const unsigned*)group_max, accum,
+                       windows, origins, n, h, w, group_size, tiles_x, (const int*)nullptr, (unsigned*)nullptr, 0u, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr);
     hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum,
                        frame, mask, depth, n, h, w, ntiles, tiles_x);
     return g3_check_launch("g3_warp_splat_resolve_f32");
@@ -1313,11 +1384,21 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
             ev_join = nullptr;
         }
     }
-    hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
-                       gmax, n, h, w, group_size, src_index);
     const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(warp_splat_windows_kernel, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
-                       (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch);
+    // fused form (default; g3_set_option("render_fused", 0) and callers that want the flow plane take the three-plane form): a z-only pre-pass for the
+    // group maxima, the projection itself inside the splat - z / flow / validity never touch memory
+    if (g3_opt_render_fused && !flow_out) {
+        hipLaunchKernelGGL(warp_zmax_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, gmax, n, h, w, group_size, src_index);
+        hipLaunchKernelGGL(warp_splat_windows_kernel<true>, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch,
+                           points_src, w2c, K, mask_src);
+    } else {
+        hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
+                           gmax, n, h, w, group_size, src_index);
+        hipLaunchKernelGGL(warp_splat_windows_kernel<false>, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
+                           (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    }
     if (ev_join) {  // join: the resolve pass applies the occlusion
         if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: stream wait failed");
         (void)hipEventDestroy(ev_join);

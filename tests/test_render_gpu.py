@@ -351,3 +351,37 @@ def test_render_items_edge_cases_vs_oracle(case):
     bad = err > (1e-4 + 1e-3 * np.abs(fr_o))
     print(f"[render edge {case}] valid px {int(got_m.sum())}; colour outliers {int(bad.sum())}/{bad.size}, max abs err {np.nanmax(err):.3e}")
     assert bad.mean() < 1e-3 and np.nanmax(err) < 5e-2
+
+
+@pytest.mark.parametrize("fg", [False, True])
+def test_fused_projection_splat_matches_the_three_plane_form(fg):
+    """Round 5: g3_render_items_f32 evaluates the projection INSIDE the splat (warp_splat_windows_kernel<true>, z-only pre-pass for the group maxima) instead
+    of writing z / flow / validity planes and reading them back. Same arithmetic, operation for operation: masks (every splat index, every validity and
+    occlusion decision) identical to the three-plane form (option render_fused = 0); colours / depths equal up to the order of the float atomics."""
+    from gen3c_amd import ops, renderer
+    dev = torch.device("cuda:0")
+    h, w, Fn = 352, 640, 6
+    depth, img, K = _scene(h, w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                    input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
+    cams = [_cam(tx=0.06 * i, tz=-0.3 * (i % 3), yaw=0.02 * i) for i in range(Fn)]
+    w2cs = torch.stack([torch.from_numpy(c) for c in cams])[None].to(dev)
+    Ks = t(K)[None, None].expand(1, Fn, 3, 3).contiguous()
+    outs = {}
+    try:
+        for fused in (1, 0, 1):
+            ops.set_option("render_fused", fused)
+            pix, msk = cache.render_cache(w2cs, Ks)
+            dep, msk_d = cache.render_cache(w2cs, Ks, render_depth=True)
+            torch.cuda.synchronize()
+            assert torch.equal(msk, msk_d)
+            outs.setdefault(fused, []).append((pix.clone(), msk.clone(), dep.clone()))
+    finally:
+        ops.set_option("render_fused", 1)
+    (p1, m1, d1), (p3, m3, d3) = outs[1]
+    p0, m0, d0 = outs[0][0]
+    assert torch.equal(m1, m0) and torch.equal(m3, m0), "masks differ between the fused and the three-plane form"
+    assert 0.2 < float(m1.mean()) < 1.0
+    for a, b in ((p1, p0), (p3, p0), (d1, d0), (d3, d0)):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"max diff {float((a - b).abs().max()):.3e}"

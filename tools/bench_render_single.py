@@ -21,8 +21,10 @@ import os
 CONFIGS = ((False, 1), (True, 1)) + (((True, 0), (True, 1)) if os.environ.get("G3_RENDER_AB") else ())
 if os.environ.get("G3_RENDER_ONLY_FG"):  # bench.py's in-run traffic passes: the benchmarked configuration only (4 renders x 32 items)
     CONFIGS = ((True, 1),)
+FUSED = int(os.environ.get("G3_RENDER_FUSED_ARM", "1"))  # 1: projection inside the splat (round 5, default); 0: z / flow / validity planes
 for fg, overlap in CONFIGS:
     ops.set_option("render_overlap", overlap)
+    ops.set_option("render_fused", FUSED)
     cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
                                     input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
     cache.render_cache(w2cs, Ks)
@@ -33,4 +35,4 @@ for fg, overlap in CONFIGS:
         pix, msk = cache.render_cache(w2cs, Ks)
     tm.stop()
     per_item = tm.elapsed_ms() / 3 / F
-    print(f"render 704x1280 foreground_masking={fg} occlusion_on_side_stream={overlap}: {per_item:.4f} ms/item = {43.2e6 / (per_item * 1e-3) / 1e9:.0f} GB/s algorithmic; coverage {float(msk.mean()):.3f}", flush=True)
+    print(f"render 704x1280 foreground_masking={fg} occlusion_on_side_stream={overlap} fused_projection={FUSED}: {per_item:.4f} ms/item = {43.2e6 / (per_item * 1e-3) / 1e9:.0f} GB/s algorithmic; coverage {float(msk.mean()):.3f}", flush=True)
