@@ -364,7 +364,7 @@ def stage_rooflines(dev):
     gbs = 43.2e6 / (per_item * 1e-3) / 1e9
     traffic = traffic_source = None  # memory-side bytes per item: QUOTED from the committed rocprofv3 PMC passes of this configuration
     try:
-        tf = next(f for f in ("r4_render_traffic.json", "r3_render_traffic.json") if (ROOT / "profiles" / f).exists())  # the latest committed PMC passes
+        tf = next(f for f in ("r5_render_traffic.json", "r4_render_traffic.json", "r3_render_traffic.json") if (ROOT / "profiles" / f).exists())  # the latest committed PMC passes
         tj = json.loads((ROOT / "profiles" / tf).read_text())
         traffic, traffic_source = tj["traffic_bytes_per_item"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
     except Exception:
@@ -379,7 +379,7 @@ def stage_rooflines(dev):
         traffic_source += f" [in-run measurement unavailable: {how}]"
     out["roofline_render"] = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(gbs, 1), frac=round(gbs / 8000.0, 4), ms_per_item=round(per_item, 4),
                                   traffic=traffic, traffic_source=traffic_source, traffic_quoted=traffic_quoted,
-                                  workload="cache render (project + splat + mesh occlusion + resolve), 704x1280 items, foreground masking, 43.2 MB algorithmic per item")
+                                  workload="cache render (z pre-pass + projecting splat + mesh occlusion + resolve), 704x1280 items, foreground masking, 43.2 MB algorithmic per item")
     return out
 
 

@@ -32,6 +32,7 @@ extern int g3_opt_gemm_unpinned;        // 1: compiler-scheduled GEMM main loop 
 extern int g3_opt_tok_tattn_px;         // tokenizer temporal attention: one wave per pixel (default 1) instead of one per (pixel, query frame)
 extern int g3_opt_gemm_persistent;      // one-wave-per-SIMD GEMM: persistent tile loop (next tile's first stage requested under the epilogue)
 extern int g3_opt_gemm_deferred;        // 1 (default): persistent one-wave-per-SIMD GEMM with the epilogue deferred into the next tile's K loop (gemm_w4e.hpp)
+extern int g3_opt_gemm_deferred_grid;    // tests: workgroups of the tile loop of the deferred-epilogue GEMM (0 = one per CU)
 extern int g3_opt_gemm_tokens_first;    // gemm_w4e.hpp: LDS-DMA piece order (0 weight rows get the two-tile lead, 1 token rows, 2 = default: token rows where N <= 4096)
 extern int g3_opt_conv_w4;              // tokenizer convolutions on the one-wave-per-SIMD kernel where it applies (default 1)
 extern int g3_opt_gemm_pingpong;        // plain K%64==0 GEMMs: 2 (default) / 1 = phase-staggered ping-pong kernel with 2 / 4 phases per K tile, 0 = classic

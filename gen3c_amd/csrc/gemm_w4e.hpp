@@ -441,7 +441,10 @@ int launch_w4e_tf(const GemmParams& p, hipStream_t stream, const char* what, int
             attr_set[dev_id] = true;
         }
     }
-    const int grid = (n_cu / 8) * 8;
+    int grid = (n_cu / 8) * 8;
+    // (tests: g3_set_option("gemm_deferred_grid", g) runs the tile loop on g workgroups - any multiple of 8 that leaves every workgroup a tile - to walk long and
+    // uneven tile lists; 0 = one workgroup per CU)
+    if (g3_opt_gemm_deferred_grid >= 8 && (g3_opt_gemm_deferred_grid % 8) == 0 && g3_opt_gemm_deferred_grid <= p.tiles_m * p.tiles_n) grid = g3_opt_gemm_deferred_grid;
     hipLaunchKernelGGL((gemm_bf16_nt_w4e_kernel<EPI, TF>), dim3(grid), dim3(GW4_THREADS), GW4E_LDS_BYTES, stream, p);
     return g3_check_launch(what);
 }

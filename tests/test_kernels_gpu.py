@@ -658,3 +658,32 @@ def test_gemm_deferred_epilogue_in_place_residual_and_strided_views():
     assert torch.equal(outs[0], outs[1])
     ref = x0.float() + gate[torch.arange(M, device=dev) % 2].float() * (a.float() @ w.float().t())
     assert _rel_l2(outs[1], ref) < 4e-3
+
+
+@pytest.mark.parametrize("grid", [8, 72, 248])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_deferred_epilogue_long_and_uneven_tile_lists(grid, epi):
+    """The deferred-epilogue kernel's tile loop on fewer workgroups than CUs (test option gemm_deferred_grid): 8 workgroups walk 66 tiles each (one per XCD:
+    66 carried epilogues in a row, one flush), 72 walk 7 or 8, 248 walk 2 or 3 - every hand-over (carry into a carrying tile, last-tile flush behind a carry)
+    at every position of the XCD-aware tile order. Bitwise equal to the non-persistent kernel."""
+    from gen3c_amd import ops
+    dev = _dev()
+    M, N, K = 8448, 4096, 2560  # 33 x 16 = 528 tiles, 40 K tiles
+    g = torch.Generator(device=dev).manual_seed(grid + epi)
+    a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    gate = torch.randn(2, N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    kw = dict(gate=gate, residual=res) if epi == 2 else {}
+    try:
+        ops.set_option("gemm_deferred", 0)
+        ref = ops.gemm_nt(a, w, epilogue=epi, **kw)
+        ops.set_option("gemm_deferred", 1)
+        ops.set_option("gemm_deferred_grid", grid)
+        out = ops.gemm_nt(a, w, epilogue=epi, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("gemm_deferred", 1)
+        ops.set_option("gemm_deferred_grid", 0)
+    diff = (out.float() - ref.float()).abs()
+    assert int((diff > 0).sum()) == 0, f"grid {grid}: {int((diff > 0).sum())} elements differ, max {float(diff.max()):.3e}"
