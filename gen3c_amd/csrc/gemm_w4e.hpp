@@ -182,15 +182,17 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4e_kernel(GemmPa
         };
         // the slices the barrier step prefetches into the L2: K tile t + D of this output tile, or of the next one behind its end
         auto with_prefetch = [&](GW4EOps o, int t) -> GW4EOps {
+#if G3_AB_GW4E_PF  // (A/B build only: the shipped kernel does not prefetch, and computing the operands would cost ~25 scalar instructions per K tile)
             const int tp = t + G3_GW4E_PFD;
             const bool in_tile = tp < nk;
             const int64_t off = (int64_t)(in_tile ? tp : tp - nk) * 128;
             o.pfb = (in_tile ? t_tile : t_next) + off;
-            o.pfwb = (in_tile ? w_tile : w_next) + off;
-            // leader (A/B build G3_AB_GW4E_PF = 3): of the workgroups an XCD runs side by side (4 token tiles x 8 feature tiles of the XCD-aware
-            // order) the one with feature tile % 8 == 0 fetches the token slice
+            // leader: of the workgroups an XCD runs side by side (4 token tiles x 8 feature tiles of the XCD-aware order) the one with feature tile % 8 == 0
             const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((((in_tile ? n0 : n0n) / BN) & 7) == 0 ? -1 : 0);
             o.pfxa = ((uint64_t)la << 32) | la;
+#else
+            (void)t;
+#endif
             return o;
         };
         auto kops = [&](auto sc, auto ksc, int t) -> GW4EOps {  // K tile t with t + 2 < nk

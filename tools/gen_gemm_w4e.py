@@ -302,8 +302,6 @@ def operand_lists(texts: list[str], extra_clobber_mem: bool = True):
             if m.group(1) not in names:
                 names.append(m.group(1))
     outs, ins = [], []
-    if any(t == "@GW4E_PFA" for t in texts):
-        names += ["pfo", "pfb", "pfxa"]
     for n in names:
         if n in ("x0", "x1", "t0", "t1", "p0", "p1", "e0", "e1", "g0", "g1", "r", "xt", "xu"):
             outs.append(f'[{n}] "=&v"({n})')
@@ -342,7 +340,8 @@ def emit_fn(name: str, texts: list[str], comment: str = "") -> str:
         else:
             body.append(f'        "{t}\\n\\t"')
     body.append("        : " + ", ".join(outs))
-    body.append("        : " + ", ".join(ins))
+    # the prefetch operands exist only in the A/B build that prefetches (macro): an unused asm input would still make the compiler compute it per K tile
+    body.append("        : " + ", ".join(ins) + (" GW4E_PF_OPERANDS" if any(t == "@GW4E_PFA" for t in texts) else ""))
     body.append('        : GW4E_OWNED, "memory");')
     if temps:
         body.append("    " + " ".join(f"(void){t};" for t in temps))
@@ -487,11 +486,13 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 #define G3_AB_GW4E_PF 0
 #endif
 #if G3_AB_GW4E_PF == 0
+#define GW4E_PF_OPERANDS
 #define GW4E_PFA ""
 #define GW4E_BARWAIT_0 "s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\t"
 #define GW4E_BARWAIT_1 "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
 #define GW4E_BARWAIT_2 "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
 #else  // 3: only the LEADER among the workgroups that share a token slice prefetches it (EXEC = 0 for the others: no request leaves the CU)
+#define GW4E_PF_OPERANDS , [pfo] "v"(o.pfo), [pfb] "s"(o.pfb), [pfxa] "s"(o.pfxa)
 #define GW4E_PFA "s_mov_b64 exec, %[pfxa]\\n\\tglobal_load_dword v55, %[pfo], %[pfb]\\n\\ts_mov_b64 exec, -1\\n\\t"
 #define GW4E_BARWAIT_0 "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
 #define GW4E_BARWAIT_1 "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
