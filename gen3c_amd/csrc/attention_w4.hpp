@@ -102,7 +102,11 @@ template <int OFF> G3_DEVICE void lds_read_frag_flip128(bf16x8& dst, uint32_t ad
 #else
 #define W4_READ "ds_read_b128 %[nf], %[addr] offset:%c[off]\n\t"
 #endif
+#ifdef G3_AB_ATTN_EXTRA_NOP  // A/B (round 5): one more issue slot per step statement = what the s_nop hipcc pads some statement boundaries with costs
+#define W4_WAIT "s_nop 0\n\ts_waitcnt lgkmcnt(%c[wn])\n\t"
+#else
 #define W4_WAIT "s_waitcnt lgkmcnt(%c[wn])\n\t"
+#endif
 #define W4_QK(h) "v_mfma_f32_32x32x16_bf16 %[s" #h "], %[f], a[%c[q" #h "]:%c[e" #h "]], %[s" #h "]\n\t"
 #define W4_QK0(h) "v_mfma_f32_32x32x16_bf16 %[s" #h "], %[f], a[%c[q" #h "]:%c[e" #h "]], %[c" #h "]\n\t"
 #define W4_PV(h) "v_mfma_f32_32x32x16_bf16 a[%c[o" #h "]:%c[g" #h "]], %[f], %[pf" #h "], a[%c[o" #h "]:%c[g" #h "]]\n\t"
