@@ -781,7 +781,7 @@ static int device_cu_count() {  // cached per device (sizes the persistent grid 
 static bool conv_w4_applies(const GemmParams& p) {
     const int64_t in_rows = (int64_t)p.cv.Ti * p.cv.Hi * p.cv.Wi;
     return g3_opt_conv_w4 && (p.K % BK) == 0 && !g3_opt_gemm_regstage && p.wide_store && (p.K / BK) * p.cv.ntaps >= 2 && p.K * 2 <= G3_ZERO_PAGE_BYTES &&
-           p.cv.kh * p.cv.kw <= 32 && in_rows < (1ll << 31) && p.lda * 2 < (1ll << 31);
+           p.cv.kh * p.cv.kw <= 32 && in_rows < (1ll << 31) && p.lda * 2 < (1ll << 31) && p.cv.w_tap_stride * 2 < (1ll << 32);
 }
 
 template <int EPI, bool CONV>

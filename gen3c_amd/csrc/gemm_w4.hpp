@@ -149,6 +149,22 @@ G3_DEVICE void gw4_kstep(uint32_t adw, uint32_t adt, const GW4Pieces& pc) {
     }
 }
 
+// K step 2 (the barrier step: no LDS-DMA pieces) of the implicit-GEMM convolution, which also moves the eight per-lane token addresses on to the next 64-channel
+// tile (+ 128 bytes) in the MFMA gaps behind the fragment reads: as compiler code between two statements the eight 64-bit adds were exposed once per K tile.
+G3_DEVICE void gw4_kstep2_bar_advance(uint32_t adw, uint32_t adt, uint64_t (&ta)[8], uint64_t step) {
+    constexpr int KS = 2;
+    constexpr int cur = GW4_FRAG0 + 32 * (KS & 1), nxt = GW4_FRAG0 + 32 * ((KS & 1) ^ 1);
+#define GW4_ADV(Q) "v_lshl_add_u64 %[ta" #Q "], %[ta" #Q "], 0, %[stp]\n\t"
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 GW4_MM(0, 0) GW4_RD(N, 4) GW4_MM(1, 0) GW4_RD(N, 5) GW4_MM(2, 0) GW4_RD(N, 6) GW4_MM(3, 0) GW4_RD(N, 7)
+                 GW4_MM(0, 1) GW4_RD(N, 0) GW4_MM(1, 1) GW4_RD(N, 1) GW4_MM(2, 1) GW4_RD(N, 2) GW4_MM(3, 1) GW4_RD(N, 3)
+                 GW4_MM(0, 2) GW4_ADV(0) GW4_MM(1, 2) GW4_ADV(1) GW4_MM(2, 2) GW4_ADV(2) GW4_MM(3, 2) GW4_ADV(3)
+                 GW4_MM(0, 3) GW4_ADV(4) GW4_MM(1, 3) GW4_ADV(5) GW4_MM(2, 3) GW4_ADV(6) GW4_MM(3, 3) GW4_ADV(7) GW4_BARRIER
+                 : [ta0] "+v"(ta[0]), [ta1] "+v"(ta[1]), [ta2] "+v"(ta[2]), [ta3] "+v"(ta[3]), [ta4] "+v"(ta[4]), [ta5] "+v"(ta[5]), [ta6] "+v"(ta[6]), [ta7] "+v"(ta[7])
+                 : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD, [stp] "s"(step) : GW4_OWNED, "memory");
+#undef GW4_ADV
+}
+
 // PERSIST (g3_set_option("gemm_persistent", 1); OFF by default - measured equal to 8 % slower in round 3, profiles/r3_gemm_persistent_ab.txt: the
 // hardware's workgroup turnover was never the cost, and the residual epilogues lose their full prefetch): one workgroup per CU walks output
 // tiles L = blockIdx.x, + gridDim.x, ... (same XCD-aware order). Between two tiles nothing of the

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
     int bt[8], yx[8];
     uint32_t smask[8];
     const uint64_t a_base = (uint64_t)(uintptr_t)p.A;
-    const uint64_t zero_base = (uint64_t)(uintptr_t)g3_zero_page;
+    uint64_t zero_base = (uint64_t)(uintptr_t)g3_zero_page;
+    asm volatile("" : "+s"(zero_base));  // resident in scalar registers: re-materialised inside the K loop it is a scalar LOAD (+ lgkmcnt wait) per tap change
     // 16-byte chunk of the 128-byte K tile this lane fetches for piece q: (lane & 7) ^ ((row >> 1) & 7), row = 64 wave + 8 q + (lane >> 3)
     const uint32_t chunk_even = (uint32_t)(((lane & 7) ^ ((lane >> 4) & 7)) * 16), chunk_odd = (uint32_t)(((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 16);
     {
@@ -129,11 +130,8 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
     };
     // odometer of the NEXT tile whose token pieces get issued: (kc, dt, dy, dx)
     int o_kc = 0, o_dt = 0, o_dy = 0, o_dx = 0;
-    auto step_tokens = [&]() {  // ta <- addresses of the following tile
-        if (++o_kc < nkc) {
-            advance_kc();
-            return;
-        }
+    auto step_tokens = [&]() {  // ta <- addresses of the following tile; the + 128 bytes of a channel-tile step were applied inside K step 2 (gw4_kstep2_bar_advance)
+        if (++o_kc < nkc) return;
         o_kc = 0;
         if (++o_dx == p.cv.kw) {
             o_dx = 0;
@@ -144,16 +142,18 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         }
         set_tap(o_dt, o_dy * p.cv.kw + o_dx, o_dy * p.cv.Wi + o_dx);
     };
-    // weight source of tile t: odometer (tap, kc) advanced once per tile, two tiles ahead of the MFMAs
+    // weight source of a K tile: RUNNING pointers for tile t + 1 and tile t + 2 (+ 128 bytes per channel tile, a jump to the next tap's slab behind a tap's
+    // last one) - a handful of scalar instructions per K tile. (Round 5: recomputing base + tap * slab + kc * 128 with 64-bit multiplies for both
+    // pointers cost ~37 scalar instructions in front of every K tile's first step: compiler code between the asm statements is exposed at one wave per SIMD.)
     const int64_t w_tap_bytes = p.cv.w_tap_stride * 2;
-    int w1_tap = 0, w1_kc = 0;  // tile t + 1
-    int w2_tap = 0, w2_kc = 0;  // tile t + 2
-    auto wsrc = [&](int tap, int kc) -> const char* { return w_tile + (int64_t)tap * w_tap_bytes + (int64_t)kc * 128; };
-    auto wstep = [&](int& tap, int& kc) {
-        if (++kc == nkc) {
-            kc = 0;
-            ++tap;
-        }
+    const uint32_t w_jump = (uint32_t)(w_tap_bytes - (int64_t)(nkc - 1) * 128);  // last channel tile of a tap -> first of the next (host: slab < 4 GiB)
+    const char* w1p = w_tile;  // tile t + 1
+    const char* w2p = w_tile;  // tile t + 2
+    int w1_kc = 0, w2_kc = 0;
+    auto wadvance = [&](const char*& wp, int& kc) {
+        const bool wrap = kc + 1 == nkc;
+        wp += wrap ? w_jump : 128u;
+        kc = wrap ? 0 : kc + 1;
     };
 
     // ---- fragment read addresses (as gemm_bf16_nt_w4_kernel)
@@ -182,14 +182,15 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)ta[q],
                                              (__attribute__((address_space(3))) void*)(uintptr_t)(m0_t + 1024u * q), 16, 0, 0);
-        wstep(w1_tap, w1_kc);  // tile 1
-        w2_tap = w1_tap; w2_kc = w1_kc;
-        wstep(w2_tap, w2_kc);  // tile 2
-        const char* w1 = wsrc(w1_tap, w1_kc);
+        wadvance(w1p, w1_kc);  // tile 1
+        w2p = w1p; w2_kc = w1_kc;
+        wadvance(w2p, w2_kc);  // tile 2
+        const char* w1 = w1p;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1 + vo_w[q]),
                                              (__attribute__((address_space(3))) void*)(uintptr_t)(m0_w + GW4_STAGE_BYTES + 1024u * q), 16, 0, 0);
+        advance_kc();   // (inside the K loop this + 128 happens in K step 2 of the previous tile)
         step_tokens();  // ta: tile 1
         static_for<0, 256>([&](auto rc) { gw4_acc_zero<decltype(rc)::value>(); });
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         G3_JITTER(wave + blockIdx.x, t);
         GW4Pieces p0{}, p1{}, p3{};
         if constexpr (DMA_N) {
-            const char* wn1 = wsrc(w1_tap, w1_kc);
+            const char* wn1 = w1p;
 #pragma unroll
             for (int q = 0; q < 2; ++q) p0.m[q] = m0_w + SN + 1024u * (6 + q), p0.vo[q] = vo_w[6 + q], p0.sb[q] = wn1;
 #pragma unroll
@@ -218,24 +219,25 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
             for (int q = 0; q < 5; ++q) p1.m[q] = m0_t + SN + 1024u * (3 + q), p1.va[q] = ta[3 + q];
         }
         if constexpr (DMA_W) {
-            const char* wn2 = wsrc(w2_tap, w2_kc);
+            const char* wn2 = w2p;
 #pragma unroll
             for (int q = 0; q < 6; ++q) p3.m[q] = m0_w + SO + 1024u * q, p3.vo[q] = vo_w[q], p3.sb[q] = wn2;
         }
         gw4_kstep<0, true, DMA_N ? 5 : 0, false, DMA_N ? 1 : 0>(adw[S][1], adt[S][1], p0);
         gw4_kstep<1, true, DMA_N ? 5 : 0, false, DMA_N ? 2 : 0>(adw[S][2], adt[S][2], p1);
         if constexpr (NEXT) {
-            gw4_kstep<2, true, 0, true>(adw[S][3], adt[S][3], p3);
+            if constexpr (DMA_N) gw4_kstep2_bar_advance(adw[S][3], adt[S][3], ta, 128ull);  // (K steps 0, 1 above issued this tile's token pieces: ta is free to move on)
+            else gw4_kstep<2, true, 0, true>(adw[S][3], adt[S][3], p3);
             gw4_kstep<3, true, DMA_W ? 6 : 0, false>(adw[S ^ 1][0], adt[S ^ 1][0], p3);
         } else {
             gw4_kstep<2, true, 0, false>(adw[S][3], adt[S][3], p3);
             gw4_kstep<3, false, 0, false>(0u, 0u, p3);
         }
         if constexpr (DMA_N) {
-            wstep(w1_tap, w1_kc);
+            wadvance(w1p, w1_kc);
             if (t + 2 < nk) step_tokens();  // (the odometer must not run past the last tap: set_tap would index outside the masks)
         }
-        if constexpr (DMA_W) wstep(w2_tap, w2_kc);
+        if constexpr (DMA_W) wadvance(w2p, w2_kc);
     };
     constexpr bool HAS_RES = (EPI == EPI_BIAS_RESIDUAL);
     const int rsub = lane >> 4, c2 = lane & 15;
