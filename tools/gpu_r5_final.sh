@@ -6,7 +6,7 @@ ROOTD=$(pwd)
 timeout 1200 python -m pytest tests -m gpu -x -q -s > gpurun_out/r5f/t_all.log 2>&1; echo "pytest rc $?" >> gpurun_out/r5f/t_all.log
 tail -3 gpurun_out/r5f/t_all.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r5f/smoke.log 2>&1; tail -2 gpurun_out/r5f/smoke.log
-timeout 600 python tools/race_screen.py --no-tokenizer > gpurun_out/r5f/race_screen.txt 2>&1; echo "rc $?" >> gpurun_out/r5f/race_screen.txt
+timeout 600 python tools/race_screen.py > gpurun_out/r5f/race_screen.txt 2>&1; echo "rc $?" >> gpurun_out/r5f/race_screen.txt
 grep -c "^ok" gpurun_out/r5f/race_screen.txt; grep "DIFF\|RACE\|rc " gpurun_out/r5f/race_screen.txt
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r5f/bench_line.json 2> gpurun_out/r5f/bench_err.log; echo "bench rc $?"
 G3_GEMM_DEFERRED=0 timeout 300 python bench.py --steps 6 --warmup 2 --no-extras --no-cpu-baseline > gpurun_out/r5f/bench_line_deferred0.json 2>> gpurun_out/r5f/bench_err.log
