@@ -34,6 +34,8 @@ int g3_opt_gemm_rowmajor_tiles = env_int("G3_GEMM_ROWMAJOR_TILES", 0);
 int g3_opt_gemm_wide_store = env_int("G3_GEMM_WIDE_STORE", 1);
 int g3_opt_splat_tiled = env_int("G3_SPLAT_TILED", 1);
 int g3_opt_render_overlap = env_int("G3_RENDER_OVERLAP", 1);
+int g3_opt_render_exclusive = env_int("G3_RENDER_EXCLUSIVE", 0);  // with render_fused: extent pre-pass + single-writer texels resolved inside the splat (less traffic, more instructions: slower)
+int g3_opt_render_full_extent = env_int("G3_RENDER_FULL_EXTENT", 1);  // g3_render_items_f32: tiles publish their unclamped rectangle, the gather pass reads the dense accumulator per texel
 int g3_opt_render_fused = env_int("G3_RENDER_FUSED", 1);  // g3_render_items_f32: projection inside the splat + z-only pre-pass (no z / flow / validity planes)
 int g3_opt_gemm_pingpong = env_int("G3_GEMM_PINGPONG", 3);  // 3: one wave per SIMD (gemm_w4.hpp) where it applies, else the 2-phase ping-pong kernel
 int g3_opt_tok_tattn_px = env_int("G3_TOK_TATTN_PX", 1);
@@ -51,6 +53,8 @@ extern "C" int g3_set_option(const char* name, int value) {
     if (!strcmp(name, "splat_tiled")) { g3_opt_splat_tiled = value; return G3_OK; }
     if (!strcmp(name, "render_overlap")) { g3_opt_render_overlap = value; return G3_OK; }
     if (!strcmp(name, "render_fused")) { g3_opt_render_fused = value; return G3_OK; }
+    if (!strcmp(name, "render_exclusive")) { g3_opt_render_exclusive = value; return G3_OK; }
+    if (!strcmp(name, "render_full_extent")) { g3_opt_render_full_extent = value; return G3_OK; }
     if (!strcmp(name, "gemm_pingpong")) { g3_opt_gemm_pingpong = value; return G3_OK; }
     if (!strcmp(name, "gemm_unpinned")) { g3_opt_gemm_unpinned = value; return G3_OK; }
     if (!strcmp(name, "conv_w4")) { g3_opt_conv_w4 = value; return G3_OK; }

@@ -37,6 +37,8 @@ extern int g3_opt_gemm_tokens_first;    // gemm_w4e.hpp: LDS-DMA piece order (0 
 extern int g3_opt_conv_w4;              // tokenizer convolutions on the one-wave-per-SIMD kernel where it applies (default 1)
 extern int g3_opt_gemm_pingpong;        // plain K%64==0 GEMMs: 2 (default) / 1 = phase-staggered ping-pong kernel with 2 / 4 phases per K tile, 0 = classic
 extern int g3_opt_gemm_wide_store;      // 1 (default): LDS-transposed full-line epilogue when the operands allow 16-byte rows
+extern int g3_opt_render_exclusive;     // 1 (needs render_fused; default 0): every tile's destination rectangle is published by a pre-pass and texels a single tile reaches are resolved inside the splat
+extern int g3_opt_render_full_extent;   // 1 (default): g3_render_items_f32's tiles publish their unclamped destination rectangle and the gather pass reads the dense accumulator per texel, not per item
 extern int g3_opt_render_fused;         // 1 (default): g3_render_items_f32 projects inside the splat (z-only pre-pass for the group maxima) instead of writing z / flow / validity planes
 extern int g3_opt_render_overlap;       // 1 (default): g3_render_items_f32 runs the occlusion pass on a side stream next to project + splat
 extern int g3_opt_splat_tiled;          // 1 (default): LDS-windowed splat; 0: direct global atomics (A/B)

@@ -103,14 +103,23 @@ __global__ __launch_bounds__(256) void warp_zmax_kernel(const float* __restrict_
     const float* K = Kmat + item * 9;
     float zmax = 0.f;
     const int stride = gridDim.x * 256;
-    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < hw; pix += stride) {
-        const int64_t so = (int64_t)sitem * hw + pix;
-        const float x = points[so * 3 + 0], y = points[so * 3 + 1], zz = points[so * 3 + 2];
-        float cam[3];
+    // four pixels per trip, their loads first: with one load per trip the pass waited out a memory latency per pixel (49 us per 16 items for 173 MB)
+    for (int pix0 = blockIdx.x * 256 + threadIdx.x; pix0 < hw; pix0 += 4 * stride) {
+        float x[4], y[4], zz[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
-        const float z = (K[6] * cam[0] + K[7] * cam[1]) + K[8] * cam[2];
-        zmax = fmaxf(zmax, fmaxf(z, 0.f));
+        for (int u = 0; u < 4; ++u) {
+            const int pix = min(pix0 + u * stride, hw - 1);  // (a repeated pixel does not change a maximum)
+            const int64_t so = (int64_t)sitem * hw + pix;
+            x[u] = points[so * 3 + 0]; y[u] = points[so * 3 + 1]; zz[u] = points[so * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float cam[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x[u] + W[i * 4 + 1] * y[u]) + W[i * 4 + 2] * zz[u]) + W[i * 4 + 3] * 1.0f;
+            const float z = (K[6] * cam[0] + K[7] * cam[1]) + K[8] * cam[2];
+            zmax = fmaxf(zmax, fmaxf(z, 0.f));
+        }
     }
     float local_max = log1pf(zmax);
 #pragma unroll
@@ -120,7 +129,10 @@ __global__ __launch_bounds__(256) void warp_zmax_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
-        atomicMax(group_max + item / group_size, __float_as_uint(m));
+        // one L2 atomic per workgroup on a handful of addresses serialises (~10 ns each, 14 080 workgroups per 16 items): most workgroups are below
+        // the running maximum and find that out with a load (a stale smaller value only costs the atomic it would have taken anyway)
+        unsigned* gm = group_max + item / group_size;
+        if (__float_as_uint(m) > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gm, __float_as_uint(m));
     }
 }
 
@@ -148,6 +160,7 @@ G3_DEVICE V3 pixel_ray(const float* Ki, int px, int py) {  // get_camera_rays: K
 G3_DEVICE int clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
 
 struct SplatGeom { int fx, cx, fy, cy; float nw, sw, ne, se; };
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 G3_DEVICE SplatGeom splat_geom(float flow_x, float flow_y, int px, int py, int h, int w) {
     const float tx = flow_x + (float)px, ty = flow_y + (float)py;  // trans_pos = flow12 + grid
@@ -339,9 +352,176 @@ G3_DEVICE int from_lane_plus32(int v) {   // lanes 0..31 receive the value of la
 }
 G3_DEVICE float from_lane_minus32(float v) { return __int_as_float(from_lane_minus32(__float_as_int(v))); }
 
+// One scan over up to NCH x 256 tile rectangles of an item (`origins` entries: origin x, y, extent x, y; x = INT_MAX: empty tile): every thread's loads
+// go out first, then ONE pair of barriers. hit(t, og) selects; the selected rectangles are handed to emit(position, t, og) in ascending tile order at
+// positions at, at + 1, ... - when all of them fit below `cap` (otherwise none is emitted). Returns the number selected.
+template <int NCH, class Hit, class Emit>
+G3_DEVICE int scan_rects(const int* __restrict__ org_item, int ntiles, int base, int* cnt_lds /* NCH x 4 ints of LDS */, int at, int cap, Hit hit, Emit emit) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int4 og[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = base + 256 * c + (int)threadIdx.x;
+        og[c] = make_int4(0x7fffffff, 0x7fffffff, 0, 0);
+        if (t < ntiles) og[c] = *reinterpret_cast<const int4*>(org_item + ORG_N * t);
+    }
+    bool h[NCH];
+    unsigned long long bal[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        h[c] = og[c].x != 0x7fffffff && hit(base + 256 * c + (int)threadIdx.x, og[c]);
+        bal[c] = __ballot(h[c]);
+        if (lane == 0) cnt_lds[c * 4 + wv] = __popcll(bal[c]);
+    }
+    __syncthreads();
+    int total = 0, off[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == wv) off[c] = total;
+            total += cnt_lds[c * 4 + i];
+        }
+    }
+    if (at + total <= cap) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (h[c]) emit(at + off[c] + __popcll(bal[c] & ((1ull << lane) - 1ull)), base + 256 * c + (int)threadIdx.x, og[c]);
+    }
+    __syncthreads();
+    return total;
+}
+
+// warp_project_kernel's arithmetic for one pixel, operation for operation (the library is built with -ffp-contract=off): world point -> camera ->
+// pixel, flow = u - px (splat_geom adds px back: the rounding of the reference's flow12 + grid), validity = mask * (z > 0). Shared by the fused
+// splat and the extent pre-pass so that both see the same floats.
+G3_DEVICE void project_pixel(const float* __restrict__ W, const float* __restrict__ K, int px, int py, float& x_flx, float& y_fly, float& z_zin, float& mk) {
+    const float x = x_flx, y = y_fly, zz = z_zin;
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
+    float pr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pr[i] = (K[i * 3 + 0] * cam[0] + K[i * 3 + 1] * cam[1]) + K[i * 3 + 2] * cam[2];
+    const float z = pr[2];
+    const float u = pr[0] / (z + 1e-7f);
+    const float v = pr[1] / (z + 1e-7f);
+    x_flx = u - (float)px;
+    y_fly = v - (float)py;
+    z_zin = z;
+    mk = mk * ((z > 0.f) ? 1.0f : 0.0f);
+}
+
+// The resolve of one texel from its five sums (forward_warp_utils_pytorch.py:660-695: normalise, nan_to_num, fill -1, clamp), with the mesh
+// occlusion's `keep` applied the way mesh_apply_kernel does. One function for the gather pass and for the splat's single-writer texels.
+struct ResolvedTexel { float c[3], m, d; };
+G3_DEVICE ResolvedTexel resolve_sums(const float (&sum)[ACC_C], bool occlusion, float keep) {
+    ResolvedTexel r;
+    float wt = sum[4];
+    if (wt != wt) wt = 1000.0f;  // nan_to_num(nan=1000)
+    const bool ok = wt > 0.f;
+    const float dval = ok ? sum[3] / wt : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = ok ? sum[c] / wt : -1.0f;
+        v = fminf(fmaxf(v, -1.0f), 1.0f);
+        if (occlusion) v = (v + 1.0f) * keep - 1.0f;
+        r.c[c] = v;
+    }
+    r.m = occlusion ? (ok ? 1.0f : 0.0f) * keep : (ok ? 1.0f : 0.0f);
+    r.d = occlusion ? dval * keep : dval;
+    return r;
+}
+
+// Extent pre-pass of the single-writer form (round 5, g3_render_items_f32 with render_exclusive = 1; replaces warp_zmax_kernel there): one
+// workgroup per SOURCE tile, the thread -> pixel map of the splat. It evaluates the projection and the corner geometry only and publishes, before
+// any tile splats, (a) the group maximum of log1p(z) the depth weights need and (b) every tile's destination rectangle (origin + used extent,
+// clamped to the window) in `origins`. With all rectangles known, a destination texel that lies in exactly ONE rectangle has a single writer: the
+// splat resolves it from LDS straight into frame / mask / depth and only texels shared between tiles make the round trip through the window
+// workspace. A rectangle wider than the window (a tile across a depth discontinuity) is published at its full size: its corners beyond the window go
+// to the dense accumulator, and the gather pass reads the accumulator for exactly those texels instead of for every pixel of a dirty item.
+__global__ __launch_bounds__(256) void warp_extent_kernel(const float* __restrict__ points, const float* __restrict__ w2c, const float* __restrict__ Kmat,
+                                                          const float* __restrict__ mask1, unsigned* __restrict__ group_max, int* __restrict__ origins,
+                                                          int n, int h, int w, int group_size, int tiles_x, const int* __restrict__ src_idx) {
+    __shared__ int red[4][4];
+    __shared__ float wave_max[4];
+    const int item = blockIdx.y;
+    const int hw = h * w;
+    const int sitem = src_idx ? src_idx[item] : item;
+    const int ty0 = (blockIdx.x / tiles_x) * TS, tx0 = (blockIdx.x % tiles_x) * TS;
+    const int64_t slot = (int64_t)item * gridDim.x + blockIdx.x;
+    const float* W = w2c + item * 16;
+    const float* K = Kmat + item * 9;
+    float x[4], y[4], zz[4], mk[4];
+    bool inb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
+        inb[k] = py < h && px < w;
+        const int pix = inb[k] ? py * w + px : 0;
+        const int64_t so = (int64_t)sitem * hw + pix;
+        x[k] = points[so * 3 + 0];
+        y[k] = points[so * 3 + 1];
+        zz[k] = points[so * 3 + 2];
+        mk[k] = mask1 ? mask1[so] : 1.0f;
+    }
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+    float zmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
+        project_pixel(W, K, px, py, x[k], y[k], zz[k], mk[k]);
+        if (inb[k]) zmax = fmaxf(zmax, fmaxf(zz[k], 0.f));  // over every pixel of the item, masked or not (warp_zmax_kernel / warp_project_kernel)
+        if (inb[k] && mk[k] != 0.f) {
+            const SplatGeom gk = splat_geom(x[k], y[k], px, py, h, w);
+            mnx = min(mnx, gk.fx);
+            mny = min(mny, gk.fy);
+            mxx = max(mxx, gk.cx);
+            mxy = max(mxy, gk.cy);
+        }
+    }
+    float local_max = log1pf(zmax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, o, 64));
+        mny = min(mny, __shfl_xor(mny, o, 64));
+        mxx = max(mxx, __shfl_xor(mxx, o, 64));
+        mxy = max(mxy, __shfl_xor(mxy, o, 64));
+        local_max = fmaxf(local_max, __shfl_xor(local_max, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        int* r = red[threadIdx.x >> 6];
+        r[0] = mnx; r[1] = mny; r[2] = mxx; r[3] = mxy;
+        wave_max[threadIdx.x >> 6] = local_max;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        // one L2 atomic per workgroup on a handful of addresses serialises (~10 ns each, 14 080 workgroups per 16 items): most workgroups are below
+        // the running maximum and find that out with a load (a stale smaller value only costs the atomic it would have taken anyway)
+        unsigned* gm = group_max + item / group_size;
+        if (__float_as_uint(m) > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gm, __float_as_uint(m));
+        const int ox = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+        const int oy = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+        int* og = origins + ORG_N * slot;
+        if (ox == 0x7fffffff) {  // nothing valid in this tile: the splat returns and the gather skips it by its origin
+            og[0] = ox; og[1] = ox; og[2] = 0; og[3] = 0;
+        } else {
+            const int fx = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2])) - ox + 1;
+            const int fy = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3])) - oy + 1;
+            // UNCLAMPED extent: the tile's window is its first min(WIN, extent) columns / rows; corners beyond it go to the dense accumulator, and
+            // the full rectangle is what tells the other tiles (and the gather pass) which texels this tile may reach
+            og[0] = ox; og[1] = oy; og[2] = fx; og[3] = fy;
+        }
+    }
+}
+
 // FUSED (round 5, g3_render_items_f32): the projection of warp_project_kernel is evaluated HERE from the points (same operation order: z, flow and validity are
 // the same floats) - the z / flow / validity planes are neither written nor read back (32 bytes per pixel and item less on the memory side).
-template <bool FUSED>
+// EXCL (round 5, with FUSED): the tile's destination rectangle comes from the extent pre-pass (warp_extent_kernel) instead of being reduced here, and
+// after the accumulation every window texel no OTHER tile's rectangle covers is resolved from LDS straight into frame / mask / depth (the arithmetic
+// of the gather pass on a single contribution: 0 + value); only shared texels are written to the window workspace.
+template <bool FUSED, bool EXCL = false>
 __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __restrict__ image, const float* __restrict__ zbuf,
                                                                  const float* __restrict__ flow, const float* __restrict__ maskz,
                                                                  const unsigned* __restrict__ group_max, float* __restrict__ accum,
@@ -349,7 +529,9 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
                                                                  int group_size, int tiles_x, const int* __restrict__ src_idx = nullptr,
                                                                  unsigned* __restrict__ dirty = nullptr, unsigned epoch = 0,
                                                                  const float* __restrict__ points = nullptr, const float* __restrict__ w2c = nullptr,
-                                                                 const float* __restrict__ Kmat = nullptr, const float* __restrict__ mask1 = nullptr) {
+                                                                 const float* __restrict__ Kmat = nullptr, const float* __restrict__ mask1 = nullptr,
+                                                                 float* __restrict__ frame = nullptr, float* __restrict__ mask_out = nullptr,
+                                                                 float* __restrict__ depth_out = nullptr, int occlusion = 0, int full_extent = 0) {
     __shared__ __attribute__((aligned(16))) float win[WIN * WIN * ACC_C];
     __shared__ int org_w[4][4];  // per-wave minima of the north-west / maxima of the south-east destination corners: window origin and extent
     __shared__ int owner[WIN * WIN];  // which pixel of the tile stores (instead of atomically adding) into a window texel: see the phases below
@@ -394,27 +576,13 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         for (int i = threadIdx.x; i < WIN * WIN; i += 256) owner[i] = -1;
     }
     if constexpr (FUSED) {
-        // warp_project_kernel's arithmetic, operation for operation (the library is built with -ffp-contract=off): world point -> camera -> pixel,
-        // flow = u - px (splat_geom adds px back: the rounding of the reference's flow12 + grid), validity = mask * (z > 0)
+        // warp_project_kernel's arithmetic (project_pixel above)
         const float* W = w2c + item * 16;
         const float* K = Kmat + item * 9;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int py = ty0 + 4 * (threadIdx.x >> 5) + k, px = tx0 + (threadIdx.x & 31);
-            const float x = flx[k], y = fly[k], zz = zin[k];
-            float cam[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) cam[i] = ((W[i * 4 + 0] * x + W[i * 4 + 1] * y) + W[i * 4 + 2] * zz) + W[i * 4 + 3] * 1.0f;
-            float pr[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) pr[i] = (K[i * 3 + 0] * cam[0] + K[i * 3 + 1] * cam[1]) + K[i * 3 + 2] * cam[2];
-            const float z = pr[2];
-            const float u = pr[0] / (z + 1e-7f);
-            const float v = pr[1] / (z + 1e-7f);
-            flx[k] = u - (float)px;
-            fly[k] = v - (float)py;
-            zin[k] = z;
-            mk[k] = mk[k] * ((z > 0.f) ? 1.0f : 0.0f);
+            project_pixel(W, K, px, py, flx[k], fly[k], zin[k], mk[k]);
         }
     }
     // Accumulate into the window. A thread owns 4 consecutive rows of one column; a wave 8 rows x 32 columns (lanes 0..31: rows 8 v .. 8 v + 3,
@@ -586,22 +754,36 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
     }
     // window origin = minimum north-west corner of the tile (per-wave minima, no initialisation pass and no LDS atomics); the barrier also
     // closes the zero fill
+    int ox, oy, ex, ey;
+    if constexpr (EXCL) {  // the extent pre-pass published the same four numbers (same geometry code, same floats)
+        const int4 og = *reinterpret_cast<const int4*>(origins + ORG_N * slot);
+        ox = og.x; oy = og.y; ex = min(WIN, og.z); ey = min(WIN, og.w);  // (published unclamped)
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, o, 64));
-        mny = min(mny, __shfl_xor(mny, o, 64));
-        mxx = max(mxx, __shfl_xor(mxx, o, 64));
-        mxy = max(mxy, __shfl_xor(mxy, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, o, 64));
+            mny = min(mny, __shfl_xor(mny, o, 64));
+            mxx = max(mxx, __shfl_xor(mxx, o, 64));
+            mxy = max(mxy, __shfl_xor(mxy, o, 64));
+        }
+        if (lane == 0) { int* ow = org_w[threadIdx.x >> 6]; ow[0] = mnx; ow[1] = mny; ow[2] = mxx; ow[3] = mxy; }
+        __syncthreads();
+        ox = min(min(org_w[0][0], org_w[1][0]), min(org_w[2][0], org_w[3][0]));
+        oy = min(min(org_w[0][1], org_w[1][1]), min(org_w[2][1], org_w[3][1]));
+        // used part of the window: only its rows are written out below and only its texels are read by the gather (a smooth flow fills ~34 x 34
+        // of the 40 x 40 texels)
+        const int fx = max(max(org_w[0][2], org_w[1][2]), max(org_w[2][2], org_w[3][2])) - ox + 1;
+        const int fy = max(max(org_w[0][3], org_w[1][3]), max(org_w[2][3], org_w[3][3])) - oy + 1;
+        ex = min(WIN, fx);
+        ey = min(WIN, fy);
+        // full_extent (g3_render_items_f32): the UNCLAMPED rectangle is published - what lies beyond the window went to the dense accumulator, and the
+        // gather pass reads the accumulator for exactly those texels instead of for every pixel of an item that has such a tile somewhere
+        if (threadIdx.x == 0) {
+            int* og = origins + ORG_N * slot;
+            og[0] = ox; og[1] = oy; og[2] = full_extent && ox != 0x7fffffff ? fx : ex; og[3] = full_extent && ox != 0x7fffffff ? fy : ey;
+        }
     }
-    if (lane == 0) { int* ow = org_w[threadIdx.x >> 6]; ow[0] = mnx; ow[1] = mny; ow[2] = mxx; ow[3] = mxy; }
-    __syncthreads();
-    const int ox = min(min(org_w[0][0], org_w[1][0]), min(org_w[2][0], org_w[3][0]));
-    const int oy = min(min(org_w[0][1], org_w[1][1]), min(org_w[2][1], org_w[3][1]));
-    // used part of the window: only its rows are written out below and only its texels are read by the gather (a smooth flow fills ~34 x 34 of
-    // the 40 x 40 texels)
-    const int ex = min(WIN, max(max(org_w[0][2], org_w[1][2]), max(org_w[2][2], org_w[3][2])) - ox + 1);
-    const int ey = min(WIN, max(max(org_w[0][3], org_w[1][3]), max(org_w[2][3], org_w[3][3])) - oy + 1);
-    if (threadIdx.x == 0) { int* og = origins + ORG_N * slot; og[0] = ox; og[1] = oy; og[2] = ex; og[3] = ey; }
     if (ox == 0x7fffffff) return;  // nothing valid in this tile: the gather skips it by its origin
     // After the merge almost every destination texel receives exactly one value. LDS float atomics cost ~6 LDS cycles per LANE (PMC), plain
     // stores 2 cycles per wave instruction, so the texels are first given an owner: every west corner still alive writes its id to
@@ -662,9 +844,80 @@ __global__ __launch_bounds__(256) void warp_splat_windows_kernel(const float* __
         }
     }
     __syncthreads();
-    f32x4* dst = reinterpret_cast<f32x4*>(windows + slot * (WIN * WIN * ACC_C));
-    const f32x4* src = reinterpret_cast<const f32x4*>(win);
-    for (int i = threadIdx.x; i < ey * (WIN * ACC_C / 4); i += 256) dst[i] = src[i];
+    if constexpr (EXCL) {
+        {
+            // which of my window's texels lie in another tile's (full) rectangle: scan the item's rectangles, keep those that meet mine in LDS (the owner map
+            // is no longer needed) and test this thread's texels (i = thread + 256 j) against them
+            constexpr int NTX = (WIN * WIN + 255) / 256;
+            bool shared_tx[NTX];
+#pragma unroll
+            for (int j = 0; j < NTX; ++j) shared_tx[j] = false;
+            unsigned* lst = reinterpret_cast<unsigned*>(owner);  // one packed word per rectangle (WIN x WIN = 1 600 of them fit; a scan selects <= 1 023)
+            const int ntiles = (int)gridDim.x;
+            const int* org_item = origins + (int64_t)item * ntiles * ORG_N;
+            for (int base = 0; base < ntiles; base += 1024) {
+                const int total = scan_rects<4>(
+                    org_item, ntiles, base, &org_w[0][0], 0, WIN * WIN,
+                    [&](int t, const int4& og) { return t != (int)blockIdx.x && og.x < ox + ex && og.x + og.z > ox && og.y < oy + ey && og.y + og.w > oy; },
+                    [&](int pos, int, const int4& og) {
+                        // the part of the other rectangle inside my window, in window coordinates (not empty: that is the hit test):
+                        // x0 | y0 << 6 | (columns - 1) << 12 | (rows - 1) << 18
+                        const int x0 = max(og.x - ox, 0), y0 = max(og.y - oy, 0);
+                        const int x1 = min(og.x - ox + og.z, WIN), y1 = min(og.y - oy + og.w, WIN);
+                        lst[pos] = (unsigned)x0 | ((unsigned)y0 << 6) | ((unsigned)(x1 - x0 - 1) << 12) | ((unsigned)(y1 - y0 - 1) << 18);
+                    });
+                for (int i = 0; i < total; ++i) {
+                    // a texel (lx | ly << 16) is inside iff the packed 16-bit differences to (x0 | y0 << 16) stay below the sizes: three VALU operations per
+                    // test (this kernel is VALU-bound)
+                    const unsigned e = lst[i];
+                    const u16x2 r0 = __builtin_bit_cast(u16x2, (e & 63u) | (((e >> 6) & 63u) << 16));
+                    const u16x2 rs = __builtin_bit_cast(u16x2, ((e >> 12) & 63u) | (((e >> 18) & 63u) << 16));
+#pragma unroll
+                    for (int j = 0; j < NTX; ++j) {
+                        const int tix = (int)threadIdx.x + 256 * j;
+                        const int ly = tix / WIN, lx = tix - ly * WIN;
+                        const u16x2 d = __builtin_bit_cast(u16x2, (unsigned)lx | ((unsigned)ly << 16)) - r0;
+                        const u16x2 m = __builtin_elementwise_min(d, rs);
+                        shared_tx[j] = shared_tx[j] || (__builtin_bit_cast(unsigned, m) == __builtin_bit_cast(unsigned, d));
+                    }
+                }
+                if (base + 1024 < ntiles) __syncthreads();  // the next scan overwrites the list
+            }
+            float* wdst = windows + slot * (WIN * WIN * ACC_C);
+#pragma unroll
+            for (int j = 0; j < NTX; ++j) {
+                const int tix = (int)threadIdx.x + 256 * j;
+                const int ly = tix / WIN, lx = tix - ly * WIN;
+                if (ly >= ey || lx >= ex) continue;
+                const float* a = win + tix * ACC_C;
+                if (shared_tx[j]) {
+#pragma unroll
+                    for (int e = 0; e < ACC_C; ++e) wdst[tix * ACC_C + e] = a[e];
+                    continue;
+                }
+                const int gy = oy + ly, gx = ox + lx;  // accumulator texel (gy, gx) = output pixel (gy - 1, gx - 1); the border ring is cropped
+                if (gy < 1 || gy > h || gx < 1 || gx > w) continue;
+                float sum[ACC_C];
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) {
+                    sum[e] = 0.f;
+                    sum[e] += a[e];  // the gather pass's 0 + value (a -0 becomes +0 there too)
+                }
+                const ResolvedTexel r = resolve_sums(sum, occlusion != 0, 1.0f);
+                const int pix = (gy - 1) * w + (gx - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) frame[((int64_t)item * 3 + c) * hw + pix] = r.c[c];
+                mask_out[(int64_t)item * hw + pix] = r.m;
+                if (depth_out) depth_out[(int64_t)item * hw + pix] = r.d;
+            }
+        }
+    } else {
+        // texel-major (r g b z weight of a texel adjacent): a planar layout was measured worse on both sides - the gather pass's row segments and the
+        // single-writer form's sparse shared texels touch five lines instead of one (+42 % fetched bytes, splat +10 %)
+        f32x4* dst = reinterpret_cast<f32x4*>(windows + slot * (WIN * WIN * ACC_C));
+        const f32x4* src = reinterpret_cast<const f32x4*>(win);
+        for (int i = threadIdx.x; i < ey * (WIN * ACC_C / 4); i += 256) dst[i] = src[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* __restrict__ windows, const int* __restrict__ origins,
@@ -672,9 +925,10 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
                                                                   float* __restrict__ mask, float* __restrict__ depth, int n, int h, int w,
                                                                   int ntiles, int tiles_x, const unsigned* __restrict__ dirty = nullptr,
                                                                   unsigned epoch = 0, unsigned* __restrict__ tmin = nullptr,
-                                                                  const float* __restrict__ Kinv = nullptr, const unsigned* __restrict__ occ_stamps = nullptr) {
+                                                                  const float* __restrict__ Kinv = nullptr, const unsigned* __restrict__ occ_stamps = nullptr,
+                                                                  int exclusive = 0) {
     __shared__ int lst[256 * 5];  // overlapping source tiles of one scan chunk: tile, ox, oy, ex, ey
-    __shared__ int wave_cnt[4];
+    __shared__ int wave_cnt[16];
     const int item = blockIdx.y;
     const int hw = h * w;
     const int aw = w + 2;
@@ -683,7 +937,9 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
     // dirty == nullptr: the caller zeroed the accumulator before the splat and it is read unconditionally (g3_warp_splat_resolve_f32).
     // Otherwise (g3_render_items_f32) the accumulator is all zero except for items the splat kernel stamped with this launch's epoch: only those
     // read it (20 bytes per pixel saved on the common path) and put the zeros back, so the buffer never needs a clearing pass.
-    const bool read_acc = dirty == nullptr || dirty[item] == epoch;
+    // exclusive: 0 = rectangles clamped to the window, accumulator read per ITEM (g3_warp_splat_resolve_f32); 2 = the rectangles are the tiles' full
+    // extents and the accumulator is read per TEXEL (below); 1 = 2 + single-writer texels (resolved by the splat, skipped here).
+    const bool read_acc = exclusive == 0 && (dirty == nullptr || dirty[item] == epoch);
     const int* org_item = origins + (int64_t)item * ntiles * ORG_N;
     const float* win_item = windows + (int64_t)item * ntiles * (WIN * WIN * ACC_C);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -693,6 +949,7 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
     bool inb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        // (a wave owning a compact 16 x 16 quadrant or an 8-row band, so that it can skip the rectangles that miss it, was measured equal or slower)
         const int py = dy0 + (threadIdx.x >> 5) + 8 * k, px = dx0 + (threadIdx.x & 31);
         inb[k] = py < h && px < w;
         gy[k] = py + 1;
@@ -709,14 +966,17 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
             for (int e = 0; e < ACC_C; ++e) a[e] = 0.f;
         }
     }
-    for (int base = 0; base < ntiles; base += 256) {
+    // the source tiles of one scan chunk (256 rectangles) whose rectangle meets this tile, compacted in ascending tile order into lst from entry
+    // `at` on (when they fit: the return value is the number of hits either way). Plain form: the rectangle is the used part of the window.
+    // Single-writer form: the tile's full extent, of which the first WIN columns / rows are its window
+    auto scan_chunk = [&](int base, int at) -> int {
         const int t = base + threadIdx.x;
         int ox = 0x7fffffff, oy = 0x7fffffff, ex = 0, ey = 0;
         if (t < ntiles) {
             const int4 og = *reinterpret_cast<const int4*>(org_item + ORG_N * t);
             ox = og.x; oy = og.y; ex = og.z; ey = og.w;
         }
-        // used window texels [oy, oy + ey) x [ox, ox + ex) against this tile's texels [dy0 + 1, dy0 + TS] x [dx0 + 1, dx0 + TS]
+        // texels [oy, oy + ey) x [ox, ox + ex) against this tile's texels [dy0 + 1, dy0 + TS] x [dx0 + 1, dx0 + TS]
         const bool hit = ox != 0x7fffffff && ox <= dx0 + TS && ox + ex > dx0 + 1 && oy <= dy0 + TS && oy + ey > dy0 + 1;
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) wave_cnt[wv] = __popcll(bal);
@@ -727,55 +987,147 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
             if (i < wv) off += wave_cnt[i];
             total += wave_cnt[i];
         }
-        if (hit) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));  // ascending tile order: the summation order below is fixed
+        if (hit && at + total <= 256) {
+            const int pos = at + off + __popcll(bal & ((1ull << lane) - 1ull));  // ascending tile order: the summation order below is fixed
             int* l = lst + 5 * pos;
             l[0] = t; l[1] = ox; l[2] = oy; l[3] = ex; l[4] = ey;
         }
         __syncthreads();
+        return total;
+    };
+    // Single-writer form: a texel inside exactly ONE tile's rectangle - and inside that tile's window - was resolved and written by that tile's splat
+    // workgroup (it is not in the window workspace); the same count decides it here. A texel in the part of a rectangle BEYOND the window received that
+    // tile's contributions through the dense accumulator: it is read (and the zero put back) for exactly those texels.
+    bool need[4];
+    int cnt[4] = {0, 0, 0, 0};
+    bool beyond[4] = {false, false, false, false};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) need[k] = inb[k];
+    auto count_entries = [&](int total) {
         for (int i = 0; i < total; ++i) {
-            const int tt = lst[5 * i], tox = lst[5 * i + 1], toy = lst[5 * i + 2], tex = lst[5 * i + 3], tey = lst[5 * i + 4];
+            const int tox = lst[5 * i + 1], toy = lst[5 * i + 2], tfx = lst[5 * i + 3], tfy = lst[5 * i + 4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lx = gx[k] - tox, ly = gy[k] - toy;
+                const bool in_rect = (unsigned)lx < (unsigned)tfx && (unsigned)ly < (unsigned)tfy;
+                cnt[k] += in_rect ? 1 : 0;
+                beyond[k] = beyond[k] || (in_rect && (lx >= WIN || ly >= WIN));
+            }
+        }
+    };
+    auto decide = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            need[k] = inb[k] && (exclusive != 1 || cnt[k] != 1 || beyond[k]);
+            if (inb[k] && beyond[k]) {
+                float* a = acc_item + ((int64_t)gy[k] * aw + gx[k]) * ACC_C;
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < ACC_C; ++e) {
+                    sum[k][e] = a[e];
+                    any = any || sum[k][e] != 0.f;
+                }
+                if (any) {
+#pragma unroll
+                    for (int e = 0; e < ACC_C; ++e) a[e] = 0.f;
+                }
+            }
+        }
+    };
+    auto sum_entries = [&](int total) {
+        for (int i = 0; i < total; ++i) {
+            const int tt = lst[5 * i], tox = lst[5 * i + 1], toy = lst[5 * i + 2];
+            const int tex = exclusive != 0 ? min(WIN, lst[5 * i + 3]) : lst[5 * i + 3], tey = exclusive != 0 ? min(WIN, lst[5 * i + 4]) : lst[5 * i + 4];
             const float* wb = win_item + (int64_t)tt * (WIN * WIN * ACC_C);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int lx = gx[k] - tox, ly = gy[k] - toy;
-                if (inb[k] && (unsigned)lx < (unsigned)tex && (unsigned)ly < (unsigned)tey) {
+                if (need[k] && (unsigned)lx < (unsigned)tex && (unsigned)ly < (unsigned)tey) {
                     const float* a = wb + (ly * WIN + lx) * ACC_C;
 #pragma unroll
                     for (int e = 0; e < ACC_C; ++e) sum[k][e] += a[e];
                 }
             }
         }
-        __syncthreads();
+    };
+    bool done = false;
+    if (exclusive != 0) {
+        // one scan when every rectangle that meets this tile fits the list (a few dozen even along a depth edge): count, decide, sum from LDS
+        int nlist = 0;
+        bool fits = true;
+        for (int base = 0; base < ntiles && fits; base += 1024) {
+            const int total = scan_rects<4>(
+                org_item, ntiles, base, wave_cnt, nlist, 256,
+                [&](int, const int4& og) { return og.x <= dx0 + TS && og.x + og.z > dx0 + 1 && og.y <= dy0 + TS && og.y + og.w > dy0 + 1; },
+                [&](int pos, int t, const int4& og) {
+                    int* l = lst + 5 * pos;
+                    l[0] = t; l[1] = og.x; l[2] = og.y; l[3] = og.z; l[4] = og.w;
+                });
+            fits = nlist + total <= 256;
+            if (fits) nlist += total;
+        }
+        if (fits) {
+            count_entries(nlist);
+            decide();
+            sum_entries(nlist);
+            done = true;
+        } else {  // otherwise chunk by chunk: once to count, once (below) to sum
+            for (int base = 0; base < ntiles; base += 256) {
+                const int total = scan_chunk(base, 0);
+                count_entries(total);
+                __syncthreads();
+            }
+            decide();
+        }
     }
+    if (!done) {
+        for (int base = 0; base < ntiles; base += 256) {
+            const int total = scan_chunk(base, 0);
+            sum_entries(total);
+            __syncthreads();
+        }
+    }
+    const bool occluded_tile = tmin && occ_stamps[(int64_t)item * ntiles + blockIdx.x] == epoch;  // the rasteriser hit this tile
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!inb[k]) continue;
         const int pix = (gy[k] - 1) * w + (gx[k] - 1);
-        float wt = sum[k][4];
-        if (wt != wt) wt = 1000.0f;  // nan_to_num(nan=1000)
-        const bool ok = wt > 0.f;
-        const float dval = ok ? sum[k][3] / wt : 0.0f;
         // mesh occlusion applied here when the rasteriser ran before this pass (g3_render_items_f32): the arithmetic of mesh_apply_kernel on the
         // values this thread is about to write, instead of a separate read-modify-write pass over frame / mask / depth
-        float keep = 1.0f;
-        if (tmin && occ_stamps[(int64_t)item * ntiles + blockIdx.x] == epoch) {  // the rasteriser hit this tile: read its tmin and leave +inf behind
+        float mesh_z = 0.f;
+        if (occluded_tile) {  // read the pixel's tmin and leave +inf behind
             const unsigned bits = tmin[(int64_t)item * hw + pix];
             if (bits != 0x7f800000u) tmin[(int64_t)item * hw + pix] = 0x7f800000u;
             const float t = (bits == 0x7f800000u) ? 0.f : __uint_as_float(bits);
             const V3 d = pixel_ray(Kinv + item * 9, gx[k] - 1, gy[k] - 1);
-            const float mesh_z = t * d.z;
+            mesh_z = t * d.z;
+        }
+        if (!need[k]) {
+            // resolved by the splat with keep = 1. An occluding triangle in front (keep = 0) turns the pixel into (v + 1) * 0 - 1 = -1, mask 0 and
+            // depth * 0: the depth the splat stored is the dval of the test (foreground masking always has a depth output)
+            if (occluded_tile) {
+                const float dval = depth[(int64_t)item * hw + pix];
+                if (((mesh_z + 0.02f) < dval) && (mesh_z > 0.f)) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) frame[((int64_t)item * 3 + c) * hw + pix] = -1.0f;
+                    mask[(int64_t)item * hw + pix] = 0.0f;
+                    depth[(int64_t)item * hw + pix] = dval * 0.0f;
+                }
+            }
+            continue;
+        }
+        float keep = 1.0f;
+        if (occluded_tile) {
+            float wt = sum[k][4];
+            if (wt != wt) wt = 1000.0f;
+            const float dval = wt > 0.f ? sum[k][3] / wt : 0.0f;  // (resolve_sums computes the same dval)
             keep = (((mesh_z + 0.02f) < dval) && (mesh_z > 0.f)) ? 0.f : 1.f;
         }
+        const ResolvedTexel r = resolve_sums(sum[k], tmin != nullptr, keep);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = ok ? sum[k][c] / wt : -1.0f;
-            v = fminf(fmaxf(v, -1.0f), 1.0f);
-            if (tmin) v = (v + 1.0f) * keep - 1.0f;
-            frame[((int64_t)item * 3 + c) * hw + pix] = v;
-        }
-        mask[(int64_t)item * hw + pix] = tmin ? (ok ? 1.0f : 0.0f) * keep : (ok ? 1.0f : 0.0f);
-        if (depth) depth[(int64_t)item * hw + pix] = tmin ? dval * keep : dval;
+        for (int c = 0; c < 3; ++c) frame[((int64_t)item * 3 + c) * hw + pix] = r.c[c];
+        mask[(int64_t)item * hw + pix] = r.m;
+        if (depth) depth[(int64_t)item * hw + pix] = r.d;
     }
 }
 
@@ -1387,23 +1739,33 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     const int tiles_x = (w + TS - 1) / TS, tiles_y = (h + TS - 1) / TS, ntiles = tiles_x * tiles_y;
     // fused form (default; g3_set_option("render_fused", 0) and callers that want the flow plane take the three-plane form): a z-only pre-pass for the
     // group maxima, the projection itself inside the splat - z / flow / validity never touch memory
-    if (g3_opt_render_fused && !flow_out) {
+    const bool exclusive = g3_opt_render_fused && !flow_out && g3_opt_render_exclusive;
+    const int full_extent = (exclusive || g3_opt_render_full_extent) ? 1 : 0;
+    if (exclusive) {
+        // single-writer form (default): the pre-pass publishes every tile's destination rectangle (and the group maxima); texels only one tile
+        // reaches are resolved by the splat itself, the window workspace carries the shared ones only (warp_extent_kernel)
+        hipLaunchKernelGGL(warp_extent_kernel, dim3(ntiles, n), dim3(256), 0, s, points_src, w2c, K, mask_src, gmax, origins, n, h, w, group_size, tiles_x,
+                           src_index);
+        hipLaunchKernelGGL((warp_splat_windows_kernel<true, true>), dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch,
+                           points_src, w2c, K, mask_src, frame, mask, depth, boundary_src ? 1 : 0);
+    } else if (g3_opt_render_fused && !flow_out) {
         hipLaunchKernelGGL(warp_zmax_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, gmax, n, h, w, group_size, src_index);
         hipLaunchKernelGGL(warp_splat_windows_kernel<true>, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch,
-                           points_src, w2c, K, mask_src);
+                           points_src, w2c, K, mask_src, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, full_extent);
     } else {
         hipLaunchKernelGGL(warp_project_kernel, dim3(min(grid_x(h * w), 256), n), dim3(256), 0, s, points_src, w2c, K, mask_src, z, flow, (float*)nullptr, maskz,
                            gmax, n, h, w, group_size, src_index);
         hipLaunchKernelGGL(warp_splat_windows_kernel<false>, dim3(ntiles, n), dim3(256), 0, s, image_src, (const float*)z, (const float*)flow, (const float*)maskz,
                            (const unsigned*)gmax, accum, windows, origins, n, h, w, group_size, tiles_x, src_index, dirty, epoch, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, full_extent);
     }
     if (ev_join) {  // join: the resolve pass applies the occlusion
         if (hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_render_items_f32: stream wait failed");
         (void)hipEventDestroy(ev_join);
     }
     hipLaunchKernelGGL(warp_gather_resolve_kernel, dim3(ntiles, n), dim3(256), 0, s, (const float*)windows, (const int*)origins, accum, frame, mask,
-                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, tmin, Kinv, (const unsigned*)occ);
+                       depth, n, h, w, ntiles, tiles_x, (const unsigned*)dirty, epoch, tmin, Kinv, (const unsigned*)occ, exclusive ? 1 : (full_extent ? 2 : 0));
     return g3_check_launch("g3_render_items_f32");
 }

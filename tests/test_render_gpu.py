@@ -385,3 +385,54 @@ def test_fused_projection_splat_matches_the_three_plane_form(fg):
     assert 0.2 < float(m1.mean()) < 1.0
     for a, b in ((p1, p0), (p3, p0), (d1, d0), (d3, d0)):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"max diff {float((a - b).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("fg", [False, True])
+@pytest.mark.parametrize("hw", [(352, 640), (203, 333)])
+def test_single_writer_splat_matches_the_window_round_trip(fg, hw):
+    """Round 5, three forms of g3_render_items_f32's splat -> gather hand-over:
+      o  (render_full_extent = 0) tiles publish rectangles clamped to their window; an item with ANY corner beyond a window is stamped dirty and the
+         gather pass reads the dense accumulator for every pixel of it (round 4);
+      f  (default) tiles publish their unclamped rectangle and the gather pass reads the accumulator for exactly the texels beyond a window;
+      x  (render_exclusive = 1) a pre-pass (warp_extent_kernel) publishes every rectangle before any tile splats; the splat resolves the texels only
+         ITS tile reaches straight into frame / mask / depth and the window workspace carries the shared texels only.
+    The decisions (splat indices, validity, occlusion) are the same code on the same floats: masks identical; colours / depths equal up to the order of
+    the LDS float atomics inside a window. The item list holds a 1.6x zoom (rectangles wider than the window everywhere) next to views with depth edges
+    (wide rectangles along them), and an odd frame size with partial tiles."""
+    from gen3c_amd import ops, renderer
+    dev = torch.device("cuda:0")
+    h, w = hw
+    Fn = 6
+    depth, img, K = _scene(h, w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, input_image=t(img)[None], input_depth=t(depth)[None, None], input_w2c=torch.eye(4, device=dev)[None],
+                                    input_intrinsics=t(K)[None], filter_points_threshold=0.05, foreground_masking=fg, input_format=["B", "C", "H", "W"])
+    cams = [_cam(tx=0.06 * i, tz=-0.3 * (i % 3), yaw=0.02 * i) for i in range(Fn)]
+    w2cs = torch.stack([torch.from_numpy(c) for c in cams])[None].to(dev)
+    Ks = t(K)[None, None].expand(1, Fn, 3, 3).contiguous().clone()
+    Ks[0, 2, :2, :2] *= 1.6  # zoomed view: destination rectangles of ~52 texels > the 40-texel window
+    forms = {"x": (1, 1), "f": (0, 1), "o": (0, 0)}
+    outs = {}
+    try:
+        for name in ("x", "f", "o", "x", "f"):
+            ops.set_option("render_exclusive", forms[name][0])
+            ops.set_option("render_full_extent", forms[name][1])
+            pix, msk = cache.render_cache(w2cs, Ks)
+            dep, msk_d = cache.render_cache(w2cs, Ks, render_depth=True)
+            torch.cuda.synchronize()
+            assert torch.equal(msk, msk_d)
+            outs.setdefault(name, []).append((pix.clone(), msk.clone(), dep.clone()))
+    finally:
+        ops.set_option("render_exclusive", 0)
+        ops.set_option("render_full_extent", 1)
+    p0, m0, d0 = outs["o"][0]
+    assert 0.2 < float(m0.mean()) < 1.0
+    for name in ("x", "f"):
+        for (p1, m1, d1) in outs[name]:
+            assert torch.equal(m1, m0), f"form {name}: masks differ from the round-4 form"
+            for a, b in ((p1, p0), (d1, d0)):
+                assert torch.isfinite(a).all()
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), f"form {name}: max diff {float((a - b).abs().max()):.3e}"
+        same = float((outs[name][0][0] == p0).float().mean())
+        print(f"[hand-over form {name} {h}x{w} fg={fg}] coverage {float(m0.mean()):.3f}; colour values bitwise equal to the round-4 form: {same:.4f}")
+        assert same > 0.98
