@@ -855,6 +855,8 @@ def main():
         })
         if cp_info is not None:
             out["cp"] = cp_info
+        out["outside_timed_region"] = ("in-run rocprofv3 PMC passes, tokenizer / renderer entries and the CPU baseline legs: rank 0, after the timed loop, "
+                                       + ("run in this invocation (n_gpus = 1)" if world == 1 else "SKIPPED in this invocation (they run at n_gpus = 1 only)"))
         if not args.no_extras and world == 1 and roof is not None and "w4b" in roof["kernel"] and (N_tok, args.blocks) == (56320, 28):
             # the dominant kernel's memory-side traffic, measured now on this box instead of quoted from a committed file (the quoted figure stays as fallback)
             measured, how = measure_attention_traffic()
