@@ -161,6 +161,7 @@ G3_DEVICE int clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi
 
 struct SplatGeom { int fx, cx, fy, cy; float nw, sw, ne, se; };
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 G3_DEVICE SplatGeom splat_geom(float flow_x, float flow_y, int px, int py, int h, int w) {
     const float tx = flow_x + (float)px, ty = flow_y + (float)py;  // trans_pos = flow12 + grid
@@ -929,6 +930,8 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
                                                                   int exclusive = 0) {
     __shared__ int lst[256 * 5];  // overlapping source tiles of one scan chunk: tile, ox, oy, ex, ey
     __shared__ int wave_cnt[16];
+    __shared__ int any_big;  // some rectangle of the list is wider than a window (only then can a texel lie beyond a window)
+    if (threadIdx.x == 0) any_big = 0;  // (ordered before the emits by the scan's first barrier)
     const int item = blockIdx.y;
     const int hw = h * w;
     const int aw = w + 2;
@@ -949,7 +952,8 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
     bool inb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // (a wave owning a compact 16 x 16 quadrant or an 8-row band, so that it can skip the rectangles that miss it, was measured equal or slower)
+        // (a wave owning a compact 16 x 16 quadrant or an 8-row band, so that it can skip the rectangles that miss it - on lane tests or on scalar
+        // compares of the list entries - was measured equal or slower, before and after the loads below were batched)
         const int py = dy0 + (threadIdx.x >> 5) + 8 * k, px = dx0 + (threadIdx.x & 31);
         inb[k] = py < h && px < w;
         gy[k] = py + 1;
@@ -1034,18 +1038,47 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
             }
         }
     };
+    // The sums, one memory round trip per rectangle: the four texels' loads go out together and unconditionally (a texel outside the rectangle reads the
+    // window's first texel - valid workspace memory - and its value is dropped by a select), then one wait, then the adds in the fixed order. With the
+    // loads behind `if (inside)` every (rectangle, texel) pair was a dependent round trip of its own and the waves spent 78 % of their cycles waiting
+    // (profiles/r3_pmc_render.txt). A rectangle none of the wave's texels lies in is skipped.
+    constexpr int SUM_U = 2;  // rectangles per trip (4: 125 registers, more dropped loads - measured 20 % slower; 1: 8 % slower)
     auto sum_entries = [&](int total) {
-        for (int i = 0; i < total; ++i) {
-            const int tt = lst[5 * i], tox = lst[5 * i + 1], toy = lst[5 * i + 2];
-            const int tex = exclusive != 0 ? min(WIN, lst[5 * i + 3]) : lst[5 * i + 3], tey = exclusive != 0 ? min(WIN, lst[5 * i + 4]) : lst[5 * i + 4];
-            const float* wb = win_item + (int64_t)tt * (WIN * WIN * ACC_C);
+        for (int i0 = 0; i0 < total; i0 += SUM_U) {
+            bool hit[SUM_U][4], any = false;
+            const float* a[SUM_U][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int lx = gx[k] - tox, ly = gy[k] - toy;
-                if (need[k] && (unsigned)lx < (unsigned)tex && (unsigned)ly < (unsigned)tey) {
-                    const float* a = wb + (ly * WIN + lx) * ACC_C;
+            for (int u = 0; u < SUM_U; ++u) {
+                const int i = min(i0 + u, total - 1);
+                const bool live = i0 + u < total;
+                const int tt = lst[5 * i], tox = lst[5 * i + 1], toy = lst[5 * i + 2];
+                const int tex = exclusive != 0 ? min(WIN, lst[5 * i + 3]) : lst[5 * i + 3], tey = exclusive != 0 ? min(WIN, lst[5 * i + 4]) : lst[5 * i + 4];
+                const float* wb = win_item + (int64_t)tt * (WIN * WIN * ACC_C);
 #pragma unroll
-                    for (int e = 0; e < ACC_C; ++e) sum[k][e] += a[e];
+                for (int k = 0; k < 4; ++k) {
+                    const int lx = gx[k] - tox, ly = gy[k] - toy;
+                    hit[u][k] = live && need[k] && (unsigned)lx < (unsigned)tex && (unsigned)ly < (unsigned)tey;
+                    a[u][k] = wb + (hit[u][k] ? (ly * WIN + lx) * ACC_C : 0);
+                    any = any || hit[u][k];
+                }
+            }
+            if (__ballot(any) == 0ull) continue;
+            float v[SUM_U][4][ACC_C];
+#pragma unroll
+            for (int u = 0; u < SUM_U; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4u q = *reinterpret_cast<const f32x4u*>(a[u][k]);  // (20-byte texels: 4-byte aligned 16-byte loads)
+                    v[u][k][0] = q.x; v[u][k][1] = q.y; v[u][k][2] = q.z; v[u][k][3] = q.w;
+                    v[u][k][4] = a[u][k][4];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SUM_U; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int e = 0; e < ACC_C; ++e) sum[k][e] = hit[u][k] ? sum[k][e] + v[u][k][e] : sum[k][e];
                 }
             }
         }
@@ -1062,12 +1095,13 @@ __global__ __launch_bounds__(256) void warp_gather_resolve_kernel(const float* _
                 [&](int pos, int t, const int4& og) {
                     int* l = lst + 5 * pos;
                     l[0] = t; l[1] = og.x; l[2] = og.y; l[3] = og.z; l[4] = og.w;
+                    if (og.z > WIN || og.w > WIN) any_big = 1;
                 });
             fits = nlist + total <= 256;
             if (fits) nlist += total;
         }
         if (fits) {
-            count_entries(nlist);
+            if (exclusive == 1 || any_big) count_entries(nlist);  // (form 2 needs the count only to find texels beyond a window)
             decide();
             sum_entries(nlist);
             done = true;
