@@ -41,7 +41,7 @@ int g3_abi_version(void);
  * default), "gemm_deferred" (1 = the persistent block GEMM with the deferred epilogue where it applies, the default; 0 = epilogue behind every K loop),
  * "gemm_persistent", "conv_w4", "attn_variant" (0 = automatic), "attn_xcd_heads", "splat_tiled", "render_overlap", "render_fused", "render_full_extent"
  * (1, default: the renderer's tiles publish unclamped destination rectangles and the gather pass reads the dense accumulator per texel),
- * "render_exclusive" (1: extent pre-pass + single-writer texels resolved inside the splat - a third less memory traffic, 15 % slower; default 0),
+ * "render_exclusive" (1: extent pre-pass + single-writer texels resolved inside the splat - a quarter less memory traffic, 18 % slower; default 0),
  * "tok_tattn_px". Outputs do not depend on them. */
 int g3_set_option(const char* name /*host*/, int value);
 int g3_device_info(int device, int* cu_count, int* is_gfx950, char* arch_name /*host*/, int arch_name_len);
