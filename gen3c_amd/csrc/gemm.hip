@@ -43,6 +43,7 @@ struct ConvGeom {
     int kt, kh, kw, st, sh, sw, ot, oh, ow;
     int ntaps;
     int64_t w_tap_stride;  // elements between consecutive tap slabs of W
+    int tap_gaps;          // gemm_w4_conv.hpp: compute a new tap's token addresses in the MFMA gaps of the barrier K step (option conv_w4 = 2: off, for A/B runs)
 };
 __device__ __attribute__((aligned(16))) unsigned g3_zero_page[2048];  // 8 KiB of zeros: source of padded taps on the LDS-DMA path (the one-wave kernel walks up to K * 2 bytes into it)
 
@@ -941,7 +942,7 @@ static int conv3d_cl(const void* in, int64_t ld_in, const void* w, int64_t ldw, 
     p.tile_order_rowmajor = g3_opt_gemm_rowmajor_tiles;
     p.wide_store = g3_opt_gemm_wide_store && !(N & 7) && !(ld_out & 7) && !((uintptr_t)out & 15) && (!bias || !((uintptr_t)bias & 15)) &&
                    (!residual || (!(ldr & 7) && !((uintptr_t)residual & 15)));
-    p.cv = ConvGeom{To, Ho, Wo, Ti, Hi, Wi, kt, kh, kw, st, sh, sw, ot, oh, ow, kt * kh * kw, (int64_t)N * ldw};
+    p.cv = ConvGeom{To, Ho, Wo, Ti, Hi, Wi, kt, kh, kw, st, sh, sw, ot, oh, ow, kt * kh * kw, (int64_t)N * ldw, g3_opt_conv_w4 != 2};
     hipStream_t s = (hipStream_t)stream;
     const char* what = "g3_conv3d_cl_bf16";
     // GroupNorm statistics of the output: in the one-wave kernel's epilogue when it runs (and a frame is at least one wave quadrant of rows),

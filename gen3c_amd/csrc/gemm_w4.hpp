@@ -165,6 +165,48 @@ G3_DEVICE void gw4_kstep2_bar_advance(uint32_t adw, uint32_t adt, uint64_t (&ta)
 #undef GW4_ADV
 }
 
+// K step 2 of the implicit-GEMM convolution at a TAP CHANGE: the eight per-lane token addresses of the next tap (gemm_w4_conv.hpp: set_tap) are
+// computed HERE, 13 VALU operations per piece spread over the 16 MFMA gaps, instead of ~110 compiler instructions (eight 64-bit multiply-adds among
+// them) exposed between two statements - once per 64-channel tile pair at 128 channels. 32-bit arithmetic: the caller guarantees input rows < 2^24
+// and an activation tensor below 4 GiB. Per piece q (E = q & 1):
+//   ti = max(bt + dt, 0); ok = ti < Ti && bit sp of smask; row = ti * frame_rows + yx + dyx; off = row * lda2 + chunk_E;
+//   address = ok ? a_base + off : zero page + chunk_E        (low / high words tl / th)
+struct GW4Tap {  // wave-uniform values of the tap (scalar registers)
+    int dt, sp, dyx, Ti, frame_rows;
+    uint32_t lda2, a_lo;
+};
+G3_DEVICE void gw4_kstep2_bar_settap(uint32_t adw, uint32_t adt, uint32_t (&tl)[8], uint32_t (&th)[8], const int (&bt)[8], const int (&yx)[8],
+                                     const uint32_t (&sm)[8], uint32_t chunk_even, uint32_t chunk_odd, uint32_t zel, uint32_t zeh, uint32_t zol,
+                                     uint32_t zoh, uint32_t a_hi, const GW4Tap& tp) {
+    constexpr int KS = 2;
+    constexpr int cur = GW4_FRAG0 + 32 * (KS & 1), nxt = GW4_FRAG0 + 32 * ((KS & 1) ^ 1);
+    uint32_t ti, b, row;
+    uint64_t cy;
+// the 13 operations of piece Q (chunk / zero page operands of its parity E), as three groups that go into consecutive gaps
+#define GW4_TAP_A(Q) "v_add_u32 %[ti], %[sdt], %[bt" #Q "]\n\tv_max_i32 %[ti], 0, %[ti]\n\tv_cmp_gt_i32 vcc, %[sTi], %[ti]\n\tv_bfe_u32 %[b], %[sm" #Q "], %[ssp], 1\n\t" \
+                     "v_cndmask_b32 %[b], 0, %[b], vcc\n\tv_mad_u32_u24 %[row], %[ti], %[sfr], %[yx" #Q "]\n\t"
+#define GW4_TAP_B(Q, E) "v_cmp_eq_u32 vcc, 1, %[b]\n\tv_add_u32 %[row], %[sdyx], %[row]\n\tv_mad_u32_u24 %[row], %[row], %[slda], %[ch" #E "]\n\t" \
+                        "v_add_co_u32 %[tl" #Q "], %[cy], %[sal], %[row]\n\tv_addc_co_u32 %[th" #Q "], %[cy], 0, %[ahi], %[cy]\n\t" \
+                        "v_cndmask_b32 %[tl" #Q "], %[zl" #E "], %[tl" #Q "], vcc\n\tv_cndmask_b32 %[th" #Q "], %[zh" #E "], %[th" #Q "], vcc\n\t"
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 GW4_MM(0, 0) GW4_RD(N, 4) GW4_TAP_A(0) GW4_MM(1, 0) GW4_RD(N, 5) GW4_TAP_B(0, 0) GW4_MM(2, 0) GW4_RD(N, 6) GW4_TAP_A(1) GW4_MM(3, 0) GW4_RD(N, 7) GW4_TAP_B(1, 1)
+                 GW4_MM(0, 1) GW4_RD(N, 0) GW4_TAP_A(2) GW4_MM(1, 1) GW4_RD(N, 1) GW4_TAP_B(2, 0) GW4_MM(2, 1) GW4_RD(N, 2) GW4_TAP_A(3) GW4_MM(3, 1) GW4_RD(N, 3) GW4_TAP_B(3, 1)
+                 GW4_MM(0, 2) GW4_TAP_A(4) GW4_MM(1, 2) GW4_TAP_B(4, 0) GW4_MM(2, 2) GW4_TAP_A(5) GW4_MM(3, 2) GW4_TAP_B(5, 1)
+                 GW4_MM(0, 3) GW4_TAP_A(6) GW4_MM(1, 3) GW4_TAP_B(6, 0) GW4_MM(2, 3) GW4_TAP_A(7) GW4_MM(3, 3) GW4_TAP_B(7, 1) GW4_BARRIER
+                 : [tl0] "=&v"(tl[0]), [tl1] "=&v"(tl[1]), [tl2] "=&v"(tl[2]), [tl3] "=&v"(tl[3]), [tl4] "=&v"(tl[4]), [tl5] "=&v"(tl[5]), [tl6] "=&v"(tl[6]), [tl7] "=&v"(tl[7]),
+                   [th0] "=&v"(th[0]), [th1] "=&v"(th[1]), [th2] "=&v"(th[2]), [th3] "=&v"(th[3]), [th4] "=&v"(th[4]), [th5] "=&v"(th[5]), [th6] "=&v"(th[6]), [th7] "=&v"(th[7]),
+                   [ti] "=&v"(ti), [b] "=&v"(b), [row] "=&v"(row), [cy] "=&s"(cy)
+                 : GW4_OPS_ALLMM, GW4_OPS_FR, GW4_OPS_RD,
+                   [bt0] "v"(bt[0]), [bt1] "v"(bt[1]), [bt2] "v"(bt[2]), [bt3] "v"(bt[3]), [bt4] "v"(bt[4]), [bt5] "v"(bt[5]), [bt6] "v"(bt[6]), [bt7] "v"(bt[7]),
+                   [yx0] "v"(yx[0]), [yx1] "v"(yx[1]), [yx2] "v"(yx[2]), [yx3] "v"(yx[3]), [yx4] "v"(yx[4]), [yx5] "v"(yx[5]), [yx6] "v"(yx[6]), [yx7] "v"(yx[7]),
+                   [sm0] "v"(sm[0]), [sm1] "v"(sm[1]), [sm2] "v"(sm[2]), [sm3] "v"(sm[3]), [sm4] "v"(sm[4]), [sm5] "v"(sm[5]), [sm6] "v"(sm[6]), [sm7] "v"(sm[7]),
+                   [ch0] "v"(chunk_even), [ch1] "v"(chunk_odd), [zl0] "v"(zel), [zh0] "v"(zeh), [zl1] "v"(zol), [zh1] "v"(zoh), [ahi] "v"(a_hi),
+                   [sdt] "s"(tp.dt), [ssp] "s"(tp.sp), [sdyx] "s"(tp.dyx), [sTi] "s"(tp.Ti), [sfr] "s"(tp.frame_rows), [slda] "s"(tp.lda2), [sal] "s"(tp.a_lo)
+                 : GW4_OWNED, "vcc", "memory");
+#undef GW4_TAP_A
+#undef GW4_TAP_B
+}
+
 // PERSIST (g3_set_option("gemm_persistent", 1); OFF by default - measured equal to 8 % slower in round 3, profiles/r3_gemm_persistent_ab.txt: the
 // hardware's workgroup turnover was never the cost, and the residual epilogues lose their full prefetch): one workgroup per CU walks output
 // tiles L = blockIdx.x, + gridDim.x, ... (same XCD-aware order). Between two tiles nothing of the

@@ -142,6 +142,13 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         }
         set_tap(o_dt, o_dy * p.cv.kw + o_dx, o_dy * p.cv.Wi + o_dx);
     };
+    // Tap changes inside the K loop (round 5): where the 32-bit form applies - input rows < 2^24, activation tensor < 4 GiB, which every tokenizer
+    // layer satisfies - the next tap's addresses are computed in the MFMA gaps of the barrier K step (gw4_kstep2_bar_settap) instead of by set_tap
+    // between two statements: at 128 channels a tap lasts two K tiles, and the ~110 exposed instructions came to a tenth of the K loop.
+    const bool tap_in_gaps = p.cv.tap_gaps && (int64_t)p.cv.Ti * frame_rows < (1ll << 24) && (int64_t)p.cv.Ti * frame_rows * lda2 + 128 < (1ll << 32) && lda2 < (1u << 24);
+    const uint64_t z_even = zero_base + chunk_even, z_odd = zero_base + chunk_odd;
+    const uint32_t zel = (uint32_t)z_even, zeh = (uint32_t)(z_even >> 32), zol = (uint32_t)z_odd, zoh = (uint32_t)(z_odd >> 32);
+    const uint32_t a_hi_v = (uint32_t)(a_base >> 32);
     // weight source of a K tile: RUNNING pointers for tile t + 1 and tile t + 2 (+ 128 bytes per channel tile, a jump to the next tap's slab behind a tap's
     // last one) - a handful of scalar instructions per K tile. (Round 5: recomputing base + tap * slab + kc * 128 with 64-bit multiplies for both
     // pointers cost ~37 scalar instructions in front of every K tile's first step: compiler code between the asm statements is exposed at one wave per SIMD.)
@@ -225,9 +232,30 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         }
         gw4_kstep<0, true, DMA_N ? 5 : 0, false, DMA_N ? 1 : 0>(adw[S][1], adt[S][1], p0);
         gw4_kstep<1, true, DMA_N ? 5 : 0, false, DMA_N ? 2 : 0>(adw[S][2], adt[S][2], p1);
+        bool tap_done = false;  // this tile's barrier step already produced the addresses of tile t + 2
         if constexpr (NEXT) {
-            if constexpr (DMA_N) gw4_kstep2_bar_advance(adw[S][3], adt[S][3], ta, 128ull);  // (K steps 0, 1 above issued this tile's token pieces: ta is free to move on)
-            else gw4_kstep<2, true, 0, true>(adw[S][3], adt[S][3], p3);
+            if constexpr (DMA_N) {  // (K steps 0, 1 above issued this tile's token pieces: ta is free to move on)
+                if (tap_in_gaps && t + 2 < nk && o_kc + 1 == nkc) {  // tile t + 2 opens a new tap
+                    o_kc = 0;
+                    if (++o_dx == p.cv.kw) {
+                        o_dx = 0;
+                        if (++o_dy == p.cv.kh) {
+                            o_dy = 0;
+                            ++o_dt;
+                        }
+                    }
+                    GW4Tap tp;
+                    tp.dt = o_dt; tp.sp = o_dy * p.cv.kw + o_dx; tp.dyx = o_dy * p.cv.Wi + o_dx; tp.Ti = p.cv.Ti; tp.frame_rows = frame_rows;
+                    tp.lda2 = lda2; tp.a_lo = (uint32_t)a_base;
+                    uint32_t tl[8], th[8];
+                    gw4_kstep2_bar_settap(adw[S][3], adt[S][3], tl, th, bt, yx, smask, chunk_even, chunk_odd, zel, zeh, zol, zoh, a_hi_v, tp);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ta[q] = ((uint64_t)th[q] << 32) | tl[q];
+                    tap_done = true;
+                } else {
+                    gw4_kstep2_bar_advance(adw[S][3], adt[S][3], ta, 128ull);
+                }
+            } else gw4_kstep<2, true, 0, true>(adw[S][3], adt[S][3], p3);
             gw4_kstep<3, true, DMA_W ? 6 : 0, false>(adw[S ^ 1][0], adt[S ^ 1][0], p3);
         } else {
             gw4_kstep<2, true, 0, false>(adw[S][3], adt[S][3], p3);
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(GW4_THREADS, 1) void gemm_bf16_nt_w4_conv_kernel(Ge
         }
         if constexpr (DMA_N) {
             wadvance(w1p, w1_kc);
-            if (t + 2 < nk) step_tokens();  // (the odometer must not run past the last tap: set_tap would index outside the masks)
+            if (t + 2 < nk && !tap_done) step_tokens();  // (the odometer must not run past the last tap: set_tap would index outside the masks)
         }
         if constexpr (DMA_W) wadvance(w2p, w2_kc);
     };

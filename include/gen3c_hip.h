@@ -39,7 +39,7 @@ const char* g3_last_error(void);
 int g3_abi_version(void);
 /* runtime switches for A/B measurements: "gemm_regstage", "gemm_rowmajor_tiles", "gemm_unpinned" (0/1), "gemm_pingpong" (3 = one wave per SIMD, the
  * default), "gemm_deferred" (1 = the persistent block GEMM with the deferred epilogue where it applies, the default; 0 = epilogue behind every K loop),
- * "gemm_persistent", "conv_w4", "attn_variant" (0 = automatic), "attn_xcd_heads", "splat_tiled", "render_overlap", "render_fused", "render_full_extent"
+ * "gemm_persistent", "conv_w4" (2 = without the in-gap tap change), "attn_variant" (0 = automatic), "attn_xcd_heads", "splat_tiled", "render_overlap", "render_fused", "render_full_extent"
  * (1, default: the renderer's tiles publish unclamped destination rectangles and the gather pass reads the dense accumulator per texel),
  * "render_exclusive" (1: extent pre-pass + single-writer texels resolved inside the splat - a quarter less memory traffic, 18 % slower; default 0),
  * "tok_tattn_px". Outputs do not depend on them. */
