@@ -270,7 +270,9 @@ _CONV_GEOMS = {  # kt, kh, kw, st, sh, sw, ot, oh, ow (gen3c_amd/tokenizer.py: _
 def test_conv_one_wave_kernel_bitwise_equals_pingpong_and_delivers_groupnorm_statistics(kind, K, N, T, H, W, res):
     """gemm_w4_conv.hpp (one wave per SIMD, gathered token rows by per-lane address) against the 8-wave ping-pong implicit GEMM it replaces:
     same accumulation order over (tap, channel) => BITWISE equal outputs, on every tokenizer geometry incl. borders (zero page), the causal
-    front replication, strides, ragged M / N tiles; and the GroupNorm statistics delivered by its epilogue against fp64 sums of the output."""
+    front replication, strides, ragged M / N tiles; and the GroupNorm statistics delivered by its epilogue against fp64 sums of the output.
+    conv_w4 = 1 (default) computes a tap change's token addresses in the MFMA gaps of the barrier K step (32-bit form), conv_w4 = 2 between two
+    statements (the form tensors of 4 GiB and more keep): both are checked."""
     from gen3c_amd import _lib, ops
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -286,7 +288,7 @@ def test_conv_one_wave_kernel_bitwise_equals_pingpong_and_delivers_groupnorm_sta
     b = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
     r = torch.randn(To, Ho, Wo, N, device=dev, generator=g).to(torch.bfloat16) if res else None
     outs = {}
-    for w4 in (1, 0):
+    for w4 in (1, 2, 0):
         ops.set_option("conv_w4", w4)
         o = torch.full((To, Ho, Wo, N), float("nan"), device=dev, dtype=torch.bfloat16)
         stats = torch.zeros(To, 2, device=dev, dtype=torch.float64)
@@ -298,9 +300,10 @@ def test_conv_one_wave_kernel_bitwise_equals_pingpong_and_delivers_groupnorm_sta
     ops.set_option("conv_w4", 1)
     assert torch.isfinite(outs[1][0].float()).all()
     assert torch.equal(outs[1][0], outs[0][0]), f"one-wave conv != ping-pong conv on {(outs[1][0] != outs[0][0]).sum().item()} elements"
+    assert torch.equal(outs[2][0], outs[0][0]), f"one-wave conv (tap change between statements) != ping-pong conv on {(outs[2][0] != outs[0][0]).sum().item()} elements"
     of = outs[1][0].double().reshape(To, -1)
     ref = torch.stack([of.sum(1), (of * of).sum(1)], dim=1)
-    for w4 in (1, 0):
+    for w4 in (1, 2, 0):
         st_ = outs[w4][1]
         err = ((st_ - ref).abs() / (ref.abs() + 1.0)).max().item()
         assert err < 2e-6, f"conv_w4={w4}: GroupNorm statistics off by {err:.2e}"
