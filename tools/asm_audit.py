@@ -276,30 +276,31 @@ def audit_attn_d512(asm_text: str):
     return findings
 
 
+def _compile_to_asm(td: Path, stem: str, extra=()):
+    out = td / (stem + ".s")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *extra, f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
+                        str(ROOT / "gen3c_amd" / "csrc" / (stem + ".hip")), "-o", str(out)], capture_output=True, text=True)
+    return r, out
+
+
 def main():
+    # the three translation units are compiled side by side (gemm.hip alone takes minutes: it bounds the audit's wall time), with the flags of
+    # gen3c_amd/build.py (PER_FILE_FLAGS: attention.hip without the SLP vectoriser)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = (("attention", ("-fno-slp-vectorize",)), ("gemm", ()), ("attention_d512", ()))
     with tempfile.TemporaryDirectory() as td:
-        out = Path(td) / "attention.s"
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
-                            str(ROOT / "gen3c_amd" / "csrc" / "attention.hip"), "-o", str(out)], capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr)
-            sys.exit(2)
-        findings = audit(out.read_text())
-        out2 = Path(td) / "gemm.s"
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
-                            str(ROOT / "gen3c_amd" / "csrc" / "gemm.hip"), "-o", str(out2)], capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr)
-            sys.exit(2)
-        findings += audit_gemm_w4(out2.read_text())
-        findings += audit_gemm_w4e(out2.read_text())
-        out3 = Path(td) / "attention_d512.s"
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",
-                            str(ROOT / "gen3c_amd" / "csrc" / "attention_d512.hip"), "-o", str(out3)], capture_output=True, text=True)
-        if r.returncode != 0:
-            print(r.stderr)
-            sys.exit(2)
-        findings += audit_attn_d512(out3.read_text())
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            done = list(ex.map(lambda j: _compile_to_asm(Path(td), *j), jobs))
+        for r, _ in done:
+            if r.returncode != 0:
+                print(r.stderr)
+                sys.exit(2)
+        (_, a_attn), (_, a_gemm), (_, a_d512) = done
+        findings = audit(a_attn.read_text())
+        gemm_text = a_gemm.read_text()
+        findings += audit_gemm_w4(gemm_text)
+        findings += audit_gemm_w4e(gemm_text)
+        findings += audit_attn_d512(a_d512.read_text())
     for f in findings:
         print("FINDING:", f)
     print("asm audit:", "clean" if not findings else f"{len(findings)} finding(s)")
