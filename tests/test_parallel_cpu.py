@@ -1,4 +1,4 @@
-"""CPU (gloo, world size 2): the context-parallel plumbing - split/cat/broadcast helpers and the all-gather-KV
+"""CPU (gloo, world sizes 2 and 8): the context-parallel plumbing - split/cat/broadcast helpers and the all-gather-KV
 head-group schedule of ContextParallelAttention - checked against the single-process oracle attention.
 The HIP kernels themselves cannot run here, so the attention/transpose callables are the oracle's (this is the one
 place a `backend` is injected; the product path never does)."""
@@ -70,7 +70,7 @@ def _worker(rank, world, port, tmp):
     try:
         # --- split / cat round trip along T
         g = torch.Generator().manual_seed(0)
-        x = torch.randn(1, 4, 6, 3, 5, generator=g)
+        x = torch.randn(1, 4, 3 * world, 3, 5, generator=g)
         xs = parallel.split_inputs_cp(x, 2, group)
         assert xs.shape == (1, 4, 3, 3, 5) and torch.equal(xs, x[:, :, rank * 3:(rank + 1) * 3])
         assert torch.equal(parallel.cat_outputs_cp(xs, 2, group), x)
@@ -81,7 +81,7 @@ def _worker(rank, world, port, tmp):
         assert parallel.broadcast(None) is None
         # --- context-parallel attention == full attention on the gathered sequence
         # S_local = 24: V gathered row-major, transposed after the exchange; S_local = 64: V^T shards gathered as key segments
-        for S, B, H in ((48, 2, 4), (64 * world, 1, 4)):
+        for S, B, H in ((24 * world, 2, 4), (64 * world, 1, 4)):
             Sl = S // world
             q = torch.randn(S * B, H * 128, generator=g)
             k = torch.randn(S * B, H * 128, generator=g)
@@ -109,8 +109,8 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_context_parallel_world2(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])  # 8 = the driver's multi-GPU run: interior ranks have key segments before AND after their own
+def test_context_parallel_world(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 

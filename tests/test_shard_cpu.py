@@ -1,4 +1,4 @@
-"""CPU (gloo, world size 2 and 3): the sharding of a chunk's replicated stages over the context-parallel ranks -
+"""CPU (gloo, world sizes 2, 3 and 8): the sharding of a chunk's replicated stages over the context-parallel ranks -
 render item PAIRS (cache_3d.py:163-183: the depth weights of bilinear_splatting are normalised per 2-item call, so a pair must stay
 on one rank) and the 2N+1 independent tokenizer encodes - must give bit-identical results to the unsharded path on every rank.
 The HIP kernels cannot run here: the renderer's forward_warp is replaced by the numpy oracle's (the one place a stand-in is injected;
@@ -103,7 +103,7 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: more ranks than tokenizer encodes / render pairs of a small chunk (ranks without a unit)
 def test_sharded_render_and_encodes(world, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
