@@ -116,13 +116,14 @@ def cpu_baseline(threads: int, blocks: int = 1):
         legs["bf16"] = dict(value=flops / dt16 / step_flops, tflops=round(flops / dt16 / 1e12, 3), seconds=round(dt16, 2))
     else:
         note16 += " - bf16 leg skipped (no native bf16 GEMM on this host), value = the fp32 leg"
-    head = legs.get("bf16", legs["fp32"])
-    prec = "bf16" if "bf16" in legs else "fp32"
+    # the baseline is the best the host does: the faster of the measured legs (a bf16 leg that ran slower than fp32 must not become the denominator)
+    prec = max(legs, key=lambda k_: legs[k_]["value"])
+    head = legs[prec]
     return dict(value=head["value"], unit="denoise-steps/sec", cores=threads, kind="port", precision=prec,
                 seconds=head["seconds"], blocks=blocks, legs=legs,
                 sample=f"oracle/dit_oracle.py: {blocks} of 28 blocks (D=4096,H=32) of one DiT forward on the configs[0] latent 16x64x64 = {N} tokens, timed in fp32 "
                        f"({dt32:.1f}s = {legs['fp32']['tflops']} TFLOP/s) and in bf16 = the reference's precision, attention through torch's fused CPU SDPA (" +
-                       (f"{legs['bf16']['seconds']}s = {legs['bf16']['tflops']} TFLOP/s" if "bf16" in legs else "skipped") + f"; {note16}); `value` = the {prec} leg, "
+                       (f"{legs['bf16']['seconds']}s = {legs['bf16']['tflops']} TFLOP/s" if "bf16" in legs else "skipped") + f"; {note16}); `value` = the faster measured leg ({prec}), "
                        f"extrapolated by FLOPs to 28 blocks x 2 forwards at 56320 tokens (the 4.419 PFLOP step); "
                        f"per-block linearity of the extrapolation checked once: profiles/r3_cpu_baseline_linearity.txt")
 
@@ -386,6 +387,69 @@ def stage_rooflines(dev):
     return out
 
 
+def video_wallclock(dev, net, ms_per_step: float, steps: int = 35):
+    """The second half of BASELINE.json's metric - wall-clock per video - for configs[1] (one 121 x 704 x 1280 chunk, 35 steps, guidance 1, one cache
+    buffer, foreground masking), rank 0, N = 1, after the timed region (gen3c_single_image.py:366-419, gen3c_pipeline.py:108-184). Everything except
+    the denoise loop is MEASURED here end to end through the product's own entry points, each once and cold as one video pays it: cache build,
+    render_cache of the 121 items, then ONE real Gen3cPipeline.generate_from_embeddings at num_steps = 1 on the bench's own 28-block network
+    (the 1 + 2 N tokenizer encodes, condition assembly, noise, the scheduler, decode, uint8 conversion and the D2H copy of the video). The denoise
+    loop is `steps` x the ms_per_step this run measured (the one step inside the 1-step generate is subtracted as measured there, so the
+    first-call allocation of that step is not charged 35 times). Model construction / checkpoint load is not part of it (the reference loads
+    once per process)."""
+    from gen3c_amd import renderer
+    from gen3c_amd.camera_utils import generate_camera_trajectory
+    from gen3c_amd.pipeline import DiffusionGen3CModel, Gen3cPipeline
+    from gen3c_amd.tokenizer import VideoTokenizer
+    H, W, T = 704, 1280, 121
+    sec = {}
+
+    def timed(name, fn_, *a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn_(*a, **k)
+        torch.cuda.synchronize()
+        sec[name] = sec.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    tk = VideoTokenizer(pixel_chunk_duration=T, device=dev)
+    tk.net.init_random(seed=1)
+    tk.register_mean_std(torch.zeros(16, 32), torch.ones(16, 32))
+    model = DiffusionGen3CModel(net, tk, latent_shape=(16, tk.get_latent_num_frames(T), H // 8, W // 8))
+    pipe = Gen3cPipeline(model, guidance=1.0, num_steps=1, height=H, width=W, fps=24, num_video_frames=T, seed=1)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev), indexing="ij")
+    depth = 3.0 + 0.001 * xs + 0.0005 * ys
+    depth[((xs - 400) ** 2 + (ys - 300) ** 2) < 120 ** 2] = 1.5
+    depth[((xs - 900) ** 2 + (ys - 420) ** 2) < 90 ** 2] = 2.2
+    img = torch.stack([torch.sin(xs / 37.0), torch.cos(ys / 23.0), torch.sin((xs + ys) / 51.0)])[None]
+    K = torch.tensor([[1000.0, 0, 640], [0, 1000.0, 352], [0, 0, 1]], device=dev)
+    w2c0 = torch.eye(4, device=dev)
+    cache = timed("cache_build", renderer.Cache3D_Buffer, frame_buffer_max=2, noise_aug_strength=0.0, input_image=img, input_depth=depth[None, None],
+                  input_w2c=w2c0[None], input_intrinsics=K[None], filter_points_threshold=0.05, foreground_masking=True, input_format=["B", "C", "H", "W"])
+    w2cs, Ks = generate_camera_trajectory("left", w2c0, K, T, 0.3, "center_facing", center_depth=3.0, device=dev)
+    renders, masks = timed("render_121_items", cache.render_cache, w2cs, Ks)
+    for name in ("encode", "decode"):
+        setattr(model, name, (lambda o, n: (lambda *a, **k: timed("tokenizer_" + n, o, *a, **k)))(getattr(model, name), name))
+    den_step = model.denoiser.denoise_step
+    model.denoiser.denoise_step = lambda *a, **k: timed("one_denoise_step_in_generate", den_step, *a, **k)
+    emb = torch.zeros(1, 512, net.crossattn_emb_channels, dtype=torch.bfloat16)
+    video = timed("generate_1_step_total", pipe.generate_from_embeddings, emb, (img[:, :, None] * 0.99).to(torch.bfloat16), renders, masks)
+    assert video.shape == (T, H, W, 3)
+    glue = sec["generate_1_step_total"] - sec.get("tokenizer_encode", 0.0) - sec.get("tokenizer_decode", 0.0) - sec.get("one_denoise_step_in_generate", 0.0)
+    non_dit = sec["cache_build"] + sec["render_121_items"] + sec.get("tokenizer_encode", 0.0) + sec.get("tokenizer_decode", 0.0) + glue
+    dit = steps * ms_per_step * 1e-3
+    total = non_dit + dit
+    sec["host_glue_in_generate"] = glue
+    del cache, renders, masks, model, pipe, tk
+    torch.cuda.empty_cache()
+    return dict(value=round(total, 2), unit="s/video", higher_is_better=False,
+                workload=f"configs[1]: one 121x704x1280 chunk, {steps} steps, guidance 1, 1 cache buffer, foreground masking, random-init weights, synthetic image + depth",
+                denoise_loop_s=round(dit, 2), non_dit_s=round(non_dit, 3), non_dit_share=round(non_dit / total, 4),
+                measured_seconds={k: round(v, 3) for k, v in sec.items()},
+                method=f"measured: cache build, render of 121 items, one Gen3cPipeline.generate_from_embeddings at num_steps=1 (tokenizer encodes + decode + host glue; its "
+                       f"own denoise step subtracted); denoise loop = {steps} x this run's ms_per_step; model construction excluded",
+                video_finite=bool(np.isfinite(video.astype(np.float32)).all()))
+
+
 def self_launch_argv(n_gpus: int, argv: list, port: int | None = None) -> list:
     """Command line that runs this script as `n_gpus` ranks of one node (used when bench.py is started bare with --gpus N>1)."""
     if port is None:
@@ -519,23 +583,50 @@ def autotune_cp(net, den, xt, cond, uncond, dev, dist, rank: int = 0, progress: 
 
 
 class _FileErrorStore:
-    """set / check / get of ONE key through a file in the node's temp directory (RunGuard's fallback side channel)."""
+    """set / check / get of keys through files in the node's temp directory (RunGuard's fallback side channel). One file per key, created 0600.
+    A leftover of an earlier run (same MASTER_PORT / run id / recycled parent pid) must not fail this one: rank 0 unlinks the files when it
+    constructs the store and at exit, and every rank ignores files older than its own start (the per-run nonce every rank has without a
+    launcher's help: no rank of THIS run can have written before the youngest rank's interpreter started, minus a clock-granularity margin)."""
 
-    def __init__(self, tag: str):
+    def __init__(self, tag: str, rank: int = 0, keys=("g3_bench_error",)):
+        import atexit
         import tempfile
-        self.path = os.path.join(tempfile.gettempdir(), f"g3_bench_error_{tag}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}")
+        self.base = os.path.join(tempfile.gettempdir(), f"g3_bench_error_{tag}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}")
+        self.path = self._file(keys[0])
+        self.t0 = time.time() - 2.0
+        if rank == 0:
+            for k in keys:
+                self._unlink(self._file(k))
+            atexit.register(lambda: [self._unlink(self._file(k)) for k in keys])
+
+    def _file(self, key) -> str:
+        return f"{self.base}_{key}"
+
+    @staticmethod
+    def _unlink(path):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
 
     def set(self, key, msg):
-        tmp = f"{self.path}.{os.getpid()}"
-        with open(tmp, "w") as f:
+        tmp = f"{self._file(key)}.{os.getpid()}"
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "w") as f:
             f.write(msg)
-        os.replace(tmp, self.path)
+        os.replace(tmp, self._file(key))
+
+    def _fresh(self, key) -> bool:
+        try:
+            return os.stat(self._file(key)).st_mtime >= self.t0
+        except OSError:
+            return False
 
     def check(self, keys):
-        return os.path.exists(self.path)
+        return all(self._fresh(k) for k in keys)
 
     def get(self, key):
-        with open(self.path, "rb") as f:
+        with open(self._file(key), "rb") as f:
             return f.read()
 
 
@@ -561,7 +652,7 @@ class RunGuard:
         if self.store is None and world > 1:
             # (private torch API gone / no default group): without a side channel a failure on rank != 0 would never reach rank 0 and the job
             # would end without a JSON line. One node, one /tmp: a file keyed by the rendezvous port does the same job.
-            self.store = _FileErrorStore(os.environ.get("MASTER_PORT", "0"))
+            self.store = _FileErrorStore(os.environ.get("MASTER_PORT", "0"), rank=rank, keys=(self.KEY,))
             print(f"bench.py: rank {rank}: no process-group store, RunGuard falls back to {self.store.path}", file=sys.stderr, flush=True)
         self._t = threading.Thread(target=self._watch, daemon=True)
         self._t.start()
@@ -858,7 +949,7 @@ def main():
         })
         if cp_info is not None:
             out["cp"] = cp_info
-        out["outside_timed_region"] = ("in-run rocprofv3 PMC passes, tokenizer / renderer entries and the CPU baseline legs: rank 0, after the timed loop, "
+        out["outside_timed_region"] = ("in-run rocprofv3 PMC passes, tokenizer / renderer entries, the wall-clock-per-video entry and the CPU baseline legs: rank 0, after the timed loop, "
                                        + ("run in this invocation (n_gpus = 1)" if world == 1 else "SKIPPED in this invocation (they run at n_gpus = 1 only)"))
         if not args.no_extras and world == 1 and roof is not None and "w4b" in roof["kernel"] and (N_tok, args.blocks) == (56320, 28):
             # the dominant kernel's memory-side traffic, measured now on this box instead of quoted from a committed file (the quoted figure stays as fallback)
@@ -873,6 +964,11 @@ def main():
                 out.update(stage_rooflines(dev))
             except Exception as e:  # the extras must never hide the measurement
                 out["roofline_extras_error"] = repr(e)
+        if not args.no_extras and world == 1 and (N_tok, args.blocks) == (56320, 28):
+            try:
+                out["video_wallclock"] = video_wallclock(dev, net, ms_per_step)
+            except Exception as e:  # the extras must never hide the measurement
+                out["video_wallclock"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 nthr = min(32, os.cpu_count() or 1)  # 32 threads measured fastest on the 2x64-core EPYC host

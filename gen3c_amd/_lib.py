@@ -13,6 +13,9 @@ _lib = None
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
+# status codes of include/gen3c_hip.h
+G3_OK, G3_ERR_ARG, G3_ERR_LAUNCH, G3_ERR_RESOURCE = 0, 1, 2, 3
+
 # name -> argtypes (restype is int unless listed in _RESTYPES). Mirrors include/gen3c_hip.h one-to-one; the
 # CPU test tests/test_abi.py checks that every symbol declared in the header is listed here and exported.
 SIGNATURES = {

@@ -380,7 +380,7 @@ extern "C" int g3_spatial_attn_d512_bf16(const void* q, const void* k, const voi
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_d512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return g3_set_error(G3_ERR_LAUNCH, "g3_spatial_attn_d512_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return g3_set_error(G3_ERR_RESOURCE, "g3_spatial_attn_d512_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(spatial_attn_d512_kernel, dim3((unsigned)(frames * p.nqb)), dim3(NT5), smem, (hipStream_t)stream, p);

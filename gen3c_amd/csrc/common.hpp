@@ -21,6 +21,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define G3_OK 0
 #define G3_ERR_ARG 1
 #define G3_ERR_LAUNCH 2
+#define G3_ERR_RESOURCE 3
 
 int g3_set_error(int code, const char* fmt, ...);
 int g3_check_launch(const char* what);

@@ -1776,7 +1776,7 @@ extern "C" int g3_render_items_f32(const float* points_src, const float* image_s
     const bool exclusive = g3_opt_render_fused && !flow_out && g3_opt_render_exclusive;
     const int full_extent = (exclusive || g3_opt_render_full_extent) ? 1 : 0;
     if (exclusive) {
-        // single-writer form (default): the pre-pass publishes every tile's destination rectangle (and the group maxima); texels only one tile
+        // single-writer form (opt-in: g3_set_option("render_exclusive", 1)): the pre-pass publishes every tile's destination rectangle (and the group maxima); texels only one tile
         // reaches are resolved by the splat itself, the window workspace carries the shared ones only (warp_extent_kernel)
         hipLaunchKernelGGL(warp_extent_kernel, dim3(ntiles, n), dim3(256), 0, s, points_src, w2c, K, mask_src, gmax, origins, n, h, w, group_size, tiles_x,
                            src_index);

@@ -274,8 +274,8 @@ class VideoExtendGeneralDIT(nn.Module):
         # every call (two concatenations per block: ~2 ms of a 1.7 s forward) instead of trusting the address.
         if self._packed is not None and self._packed["key"] == key and self._packed["versioned"]:
             return self._packed
-        if self._packed is not None:
-            self._tables.clear()  # the position tables derive from the pos-emb parameters
+        if self._packed is not None and self._packed["key"] != key:
+            self._tables.clear()  # the position tables derive from the pos-emb parameters (an unversioned re-fuse of the SAME storages keeps them)
         P = dict(self.named_parameters())
         blocks = []
         for i in range(self.num_blocks):
@@ -516,7 +516,9 @@ class VideoExtendGeneralDIT(nn.Module):
         (weight set, context tensor) and reused by the 2 x 35 forwards of a chunk (28 x 2 x 4.3 MB per context). The cache key is
         the context tensor's storage address + in-place version counter + shape / dtype; a new prompt tensor or an in-place edit
         rebuilds the entry."""
-        use_cache = cacheable(crossattn_emb)  # inference tensors: no version counter -> recompute (see tensor_version)
+        # inference tensors: no version counter -> recompute (see tensor_version); the same holds for the WEIGHTS: an unversioned weight set
+        # (pk["versioned"] False) can have to_k / to_v edited in place behind an unchanged pk["key"]
+        use_cache = cacheable(crossattn_emb) and pk["versioned"]
         key = (crossattn_emb.data_ptr(), tensor_version(crossattn_emb), tuple(crossattn_emb.shape), crossattn_emb.dtype, pk["key"])
         cache = self.__dict__.setdefault("_ca_kv_cache", {})
         hit = cache.get(key) if use_cache else None

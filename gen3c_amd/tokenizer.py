@@ -245,6 +245,8 @@ class CausalVideoTokenizerNet(torch.nn.Module):
             rc = lib.g3_spatial_attn_d512_bf16(_ptr(q), _ptr(k), _ptr(vT), T * HW, HW, _ptr(o), T, HW, float(C) ** -0.5, _st())
             if rc == 0:
                 return self._conv(o.view(T, H, W, C), f"{name}.proj_out", "p1", residual=x, stats=True)
+            if rc not in (_lib.G3_ERR_ARG, _lib.G3_ERR_RESOURCE):
+                _lib.check(rc, "g3_spatial_attn_d512_bf16")  # a launch failure / sticky device error is not a refusal: raise here, under its own name
             # (148 KB of dynamic LDS refused, a clip beyond the kernel's 32-bit offsets): the three-kernel HIP path below computes the same
             # attention; say so once - a silent 2x slowdown of this stage would otherwise go unnoticed
             if not getattr(self, "_flash_warned", False):

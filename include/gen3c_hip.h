@@ -27,6 +27,7 @@ extern "C" {
 #define G3_OK 0
 #define G3_ERR_ARG 1
 #define G3_ERR_LAUNCH 2
+#define G3_ERR_RESOURCE 3 /* the device refused a static resource request (dynamic LDS size): the caller may take another path */
 
 /* epilogues of g3_gemm_bf16_nt */
 #define G3_EPI_NONE 0           /* C = A.W^T                                   */

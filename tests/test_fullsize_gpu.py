@@ -73,12 +73,17 @@ def test_gemm_full_size_sampled_rows_and_row_subsets(N, K, epi):
     assert torch.equal(out_sub, out[sub])
 
 
-def _bench_launch_operands(dev, H=32, B=2, seed=11):
-    """The operands of the benchmark's self-attention launch, produced the way the DiT forward produces them: ONE fused QKV projection
-    (g3_gemm_qk_norm_rope_bf16) writes q | k (per-head RMSNorm + RoPE in the epilogue) into a [S*B, 3*H*128] buffer and the v heads
-    straight into V^T. q / k handed to the attention kernel are strided column views of that buffer (k offsets reach 2.77 GB of the
-    kernel's 32-bit byte-offset budget at H = 32, B = 2)."""
-    from gen3c_amd import ops
+def _bench_launch_operands(dev, H=32, B=2, seed=11, chain="default"):
+    """The operands of the benchmark's self-attention launch, produced the way the DiT forward produces them (gen3c_amd/dit.py, the branch
+    `_FUSE_QKV_EPILOGUE` selects; chain="default" follows the product's default, whatever it is):
+      * "separate" (the default since round 3): ONE plain QKV projection into a [S*B, 3*H*128] buffer, then q and k normalised + rotated IN PLACE
+        by g3_qk_rmsnorm_rope_bf16 on strided column views of it and the v columns transposed into V^T by g3_transpose_v_bf16;
+      * "fused": g3_gemm_qk_norm_rope_bf16 does all three in the projection's epilogue.
+    Either way q / k handed to the attention kernel are strided column views of the buffer (k offsets reach 2.77 GB of the kernel's 32-bit
+    byte-offset budget at H = 32, B = 2; the in-place norm passes address the same range)."""
+    from gen3c_amd import dit, ops
+    if chain == "default":
+        chain = "fused" if dit._FUSE_QKV_EPILOGUE else "separate"
     g = torch.Generator(device=dev).manual_seed(seed)
     Dm = H * HD
     h = torch.randn(S * B, Dm, device=dev, generator=g).to(torch.bfloat16)
@@ -89,13 +94,20 @@ def _bench_launch_operands(dev, H=32, B=2, seed=11):
     ang = torch.cat([ang, ang], dim=-1)
     cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
     vt = torch.zeros(B, H, HD, ops.ceil_to(S, 64), device=dev, dtype=torch.bfloat16)
-    qkv = ops.gemm_qk_norm_rope(h, w, Dm, Dm, nq, nk, cos, sin, S, B, vt=vt)
-    return dict(h=h, w=w, nq=nq, nk=nk, ang=ang, qkv=qkv, vt=vt, Dm=Dm)
+    if chain == "fused":
+        qkv = ops.gemm_qk_norm_rope(h, w, Dm, Dm, nq, nk, cos, sin, S, B, vt=vt)
+    else:
+        assert chain == "separate"
+        qkv = ops.gemm_nt(h, w)
+        ops.qk_rmsnorm_rope(qkv[:, :Dm], nq, cos, sin, S, B, H, out=qkv[:, :Dm])
+        ops.qk_rmsnorm_rope(qkv[:, Dm:2 * Dm], nk, cos, sin, S, B, H, out=qkv[:, Dm:2 * Dm])
+        ops.transpose_v(qkv[:, 2 * Dm:], S, B, H, out=vt)
+    return dict(h=h, w=w, nq=nq, nk=nk, ang=ang, qkv=qkv, vt=vt, Dm=Dm, chain=chain)
 
 
 def test_bench_attention_launch_w4b_xcd_grid_vs_fp32():
     """the launch bench.py times - flash_attn_fwd_w4b_kernel<true>, 1-D XCD-local grid, S = 56 320, H = 32, B = 2,
-    q / k as column views of the fused QKV buffer, V^T written by the QKV epilogue - against an fp32 softmax on sampled rows.
+    q / k as column views of the fused QKV buffer, V^T as the product's default QKV chain writes it - against an fp32 softmax on sampled rows.
     (batch, head) pair hb = b*H + h is worked on by XCD hb % 8 (attention_w4b.hpp): the 8 checked pairs cover all 8 XCDs, both batch
     items, the first and the last head. 256 sampled rows per pair: the first / last row block (prologue and ragged tail paths) + random ones."""
     from gen3c_amd import _lib, ops
@@ -129,13 +141,18 @@ def test_bench_attention_launch_w4b_xcd_grid_vs_fp32():
     print(f"[bench attention launch w4b<true> S=56320 H=32 B=2] worst rel-L2 over 8 (batch, head) pairs = {worst:.3e}")
 
 
-def test_bench_qkv_epilogue_vs_fp32_norm_rope():
-    """The fused QKV epilogue at the benchmark size (S = 56 320, B = 2, D = 4096) against an fp32 evaluation of Attention.cal_qkv
-    (attention.py:247-280: Linear, per-head RMSNorm with weight, non-interleaved RoPE; v plain) on sampled rows - not against the unfused kernels."""
+@pytest.mark.parametrize("chain", ["separate", "fused"])
+def test_bench_qkv_epilogue_vs_fp32_norm_rope(chain):
+    """Both forms of the QKV chain at the benchmark size (S = 56 320, B = 2, D = 4096) - "separate" = what the DiT forward runs by default (plain
+    projection, in-place norm + RoPE passes over 2.77 GB of strided views, V transpose), "fused" = the opt-in epilogue - against an fp32 evaluation
+    of Attention.cal_qkv (attention.py:247-280: Linear, per-head RMSNorm with weight, non-interleaved RoPE; v plain) on sampled rows, and against
+    each other: the two chains share every rounding point, so their outputs are bitwise equal."""
+    from gen3c_amd import dit
     from oracle import dit_oracle
     dev = torch.device("cuda:0")
     H, B = 32, 2
-    op = _bench_launch_operands(dev, H, B, seed=12)
+    assert ("fused" if dit._FUSE_QKV_EPILOGUE else "separate") in ("separate", "fused")
+    op = _bench_launch_operands(dev, H, B, seed=12, chain=chain)
     Dm, qkv, vt = op["Dm"], op["qkv"], op["vt"]
     g = torch.Generator(device=dev).manual_seed(5)
     srow = torch.cat([torch.arange(0, 16, device=dev), torch.randint(16, S - 16, (96,), device=dev, generator=g), torch.arange(S - 16, S, device=dev)])  # tokens
@@ -155,6 +172,9 @@ def test_bench_qkv_epilogue_vs_fp32_norm_rope():
         assert r < 4e-3, f"v^T (b={b}): rel-L2 {r:.3e}"
     if vt.shape[-1] > S:
         assert float(vt[:, :, :, S:].float().abs().max()) == 0.0  # the zero tail the attention kernel relies on
+    if chain == "fused":  # the two chains share every rounding point: bitwise equal at full size too (q | k columns and V^T)
+        other = _bench_launch_operands(dev, H, B, seed=12, chain="separate")
+        assert torch.equal(other["qkv"][:, :2 * Dm], qkv[:, :2 * Dm]) and torch.equal(other["vt"], vt)
 
 
 def test_dit_full_size_single_block_vs_fp32_oracle():

@@ -1,0 +1,126 @@
+"""GPU parity on the reference's OWN input data: every other tokenizer / renderer test feeds synthetic noise or
+analytic scenes; here the HIP path sees natural-image statistics (GroupNorm over real image content, peaked spatial attention over coherent
+structure - layers3d.py:345-383 -, depth edges along ragged object outlines) from the two data files the reference ships for this path:
+assets/diffusion/000000.png (the single-image example input) and tokenizer/test_data/image.png (tests/golden/ref_inputs/, byte copies).
+
+* renderer: 000000.png at 704 x 1280 -> Cache3D_Buffer -> render_cache vs oracle/warp_oracle.py: flow / masks BIT-EXACT, colours within the
+  atomics' tolerance; with and without foreground masking (the mesh over ~24 000 boundary triangles of the image's own outlines vs the brute force).
+* tokenizer: the reference test's shape 17 x 512 x 512 (layers3d_test.py:32-114) as a camera pan over 000000.png and as image.png held still,
+  plus image.png as a single frame - encode / decode vs the fp32 oracle.
+Weights are random (no checkpoint exists in any environment); the INPUT statistics are what this file adds."""
+import numpy as np
+import pytest
+import torch
+
+from tests import ref_fixture_inputs as rf
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def _render_inputs():
+    h, w = 704, 1280
+    rgb = rf.load_rgb("diffusion_000000.png", size=(w, h))
+    depth = rf.pseudo_depth(rgb)
+    K = np.array([[1000, 0, w / 2], [0, 1000, h / 2], [0, 0, 1]], np.float32)
+    return h, w, rf.to_unit(rgb), depth, K
+
+
+@pytest.mark.parametrize("fg", [False, True])
+def test_render_cache_on_reference_image_vs_oracle(fg):
+    """One reference pair (2 target cameras: a lateral move and a move + yaw) of a 1-buffer cache built from 000000.png; masks bit-exact."""
+    from gen3c_amd import renderer
+    from oracle import warp_oracle as wo
+    dev = torch.device("cuda:0")
+    h, w, img, depth, K = _render_inputs()
+    cache = renderer.Cache3D_Buffer(frame_buffer_max=2, noise_aug_strength=0, input_image=_t(img, dev)[None], input_depth=_t(depth, dev)[None, None],
+                                    input_w2c=torch.eye(4, device=dev)[None], input_intrinsics=_t(K, dev)[None], filter_points_threshold=0.05,
+                                    foreground_masking=fg, input_format=["B", "C", "H", "W"])
+    w2cs = np.stack([np.eye(4, dtype=np.float32) for _ in range(2)])
+    w2cs[0, 0, 3] = -0.12
+    c, s = np.cos(0.06), np.sin(0.06)
+    w2cs[1, :3, :3] = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    w2cs[1, :3, 3] = (-0.3, 0.02, -0.1)
+    pix, msk = cache.render_cache(_t(w2cs, dev)[None], _t(K, dev)[None, None].expand(1, 2, 3, 3))
+    torch.cuda.synchronize()
+    assert pix.shape == (1, 2, 1, 3, h, w) and msk.shape == (1, 2, 1, 1, h, w)
+
+    pts = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    rel = wo.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    bnd = ~wo.reliable_depth_mask(depth[None, None])[0, 0]
+    assert 0.5 < rel.mean() < 0.97 and bnd.sum() > 20000, "the image's depth layers must leave ragged, long boundaries"
+    b2 = lambda a: np.broadcast_to(a, (2,) + a.shape[1:])
+    kw = dict(foreground_masking=True, boundary_mask=b2(bnd[None]), ray_triangle_fn=wo.ray_triangle_depth_c) if fg else {}
+    fr, m2, _, _, _ = wo.forward_warp(b2(img[None]), b2(rel), b2(pts), w2cs, b2(K[None]), **kw)
+    if fg:
+        _, m_plain, _, _, _ = wo.forward_warp(b2(img[None]), b2(rel), b2(pts), w2cs, b2(K[None]))
+        removed = (m_plain != m2).sum(axis=(1, 2, 3))
+        assert removed.min() > 500, f"mesh occlusion must actually remove pixels in both items: {removed}"
+    got_m = msk[0, :, 0].cpu().numpy()
+    nd = int((got_m != m2).sum())
+    got = pix[0, :, 0].cpu().numpy()
+    err = np.abs(got - fr)
+    bad = err > (1e-4 + 1e-3 * np.abs(fr))
+    print(f"[render 000000.png 704x1280 fg={fg}] valid {m2.mean():.3f}; mask px differing {nd}; colour outliers {int(bad.sum())}/{bad.size}, max abs err {err.max():.3e}")
+    assert nd == 0, f"mask differs on {nd} px"
+    assert bad.mean() < 1e-5 and err.max() < 5e-2
+
+
+def _clip(case):
+    if case == "pan17":  # a camera pan over 000000.png, the reference test's shape
+        return rf.pan_clip(rf.load_rgb("diffusion_000000.png"), 17, 512, 512, step=4)
+    if case == "still17":  # tokenizer/test_data/image.png held for 17 frames
+        fr = rf.to_unit(rf.centre_crop(rf.load_rgb("tokenizer_image.png"), 512, 512))
+        return np.repeat(fr[:, None], 17, axis=1)
+    assert case == "image1"  # the whole test image as ONE frame (764 -> 752 rows: multiple of 16), mid level 94 x 128
+    return rf.to_unit(rf.centre_crop(rf.load_rgb("tokenizer_image.png"), 752, 1024))[:, None]
+
+
+@pytest.mark.parametrize("case", ["pan17", "still17", "image1"])
+def test_tokenizer_on_reference_images_vs_fp32_oracle(case):
+    """VideoTokenizer.encode / .decode (the plug-in surface, pretrained_vae.py:342-405) on the reference's own images vs oracle/tokenizer_oracle.py in fp32
+    on the same device. Shapes as layers3d_test.py:96-113 asserts them."""
+    from gen3c_amd.tokenizer import VideoTokenizer
+    from oracle import tokenizer_oracle as tok
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(_clip(case))[None].to(torch.bfloat16)
+    T, H, W = x.shape[2:]
+    tk = VideoTokenizer(pixel_chunk_duration=T, channels=128, device=dev)
+    sd = tk.net.init_random(seed=11)
+    sd32 = {k: v.to(torch.bfloat16).float().to(dev) for k, v in sd.items()}
+    tl = (T - 1) // 8 + 1
+    g = torch.Generator().manual_seed(7)
+    mean = torch.randn(16, tl, generator=g) * 0.1
+    std = torch.rand(16, tl, generator=g) * 0.5 + 0.75
+    tk.register_mean_std(mean, std)
+    if T == 1:
+        tk.register_image_mean_std(mean[:, 0], std[:, 0])
+    z = tk.encode(x.to(dev))
+    torch.cuda.synchronize()
+    assert tuple(z.shape) == (1, 16, tl, H // 8, W // 8)
+    m32 = mean.to(torch.bfloat16).float().view(1, 16, tl, 1, 1).to(dev)
+    s32 = std.to(torch.bfloat16).float().view(1, 16, tl, 1, 1).to(dev)
+    tok.CONV_IMPL = "taps"  # the oracle's per-tap matmul form (== F.conv3d: tests/test_tokenizer_oracle_golden.py); the vendor's fp32 conv3d can fall back to a naive kernel
+    try:
+        with torch.no_grad():
+            z_ref = tok.encode(sd32, x.float().to(dev), m32, s32)
+            zin = z_ref.to(torch.bfloat16)
+            y_ref = tok.decode(sd32, zin.float(), m32, s32)
+    finally:
+        tok.CONV_IMPL = "torch"
+    y = tk.decode(zin)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(x.shape)
+    rz, ry = _rel(z, z_ref), _rel(y, y_ref)
+    # what makes natural content different from noise: a few GroupNorm groups / attention rows dominated by large coherent regions
+    print(f"[tokenizer on reference image, {case} {T}x{H}x{W}] encode rel_l2={rz:.3e}  decode rel_l2={ry:.3e}  |x| mean {float(x.float().abs().mean()):.3f}")
+    assert torch.isfinite(z.float()).all() and torch.isfinite(y.float()).all()
+    assert rz <= 1.5e-2 and ry <= 1.8e-2  # the bars of test_plugin_encode_decode_reference_test_shape (noise input, same depth and arithmetic)
