@@ -43,6 +43,7 @@ SIGNATURES = {
     "g3_layernorm_modulate_bf16": [vp, i64, vp, vp, i64, i32, vp, i64, i32, i32, f32, vp],
     "g3_posemb_layernorm_modulate_bf16": [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i64, i32, vp, i64, i32, f32, vp],
     "g3_qk_rmsnorm_rope_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp],
+    "g3_qk_rmsnorm_rope_pair_bf16": [vp, i64, vp, i32, vp, i32, vp, vp, vp, i64, i32, i32, i32, f32, vp],
     "g3_gemm_qk_norm_rope_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, i64, vp],
     "g3_add_inplace_bf16": [vp, vp, i64, vp],
     "g3_warp_project_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

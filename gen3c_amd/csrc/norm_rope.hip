@@ -136,10 +136,65 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restr
 // cos/sin tables are fp32 [S][128] (row = sequence position, shared by all batches/heads); nullptr = no RoPE.
 // One thread owns 8 dims of the first half and the matching 8 of the second half; 8 threads per head.
 // ----------------------------------------------------------------------------------------------------------
-// `in` and `out` are NOT __restrict__: the DiT runs this kernel IN PLACE on the q | k columns of the fused QKV buffer (out == in,
+// The arithmetic of one (row, head): this thread's 8 dims of the first rotary half (a) and the matching 8 of the second (b). ONE body for both kernels
+// below, so that they are bitwise equal by construction (-ffp-contract=off: no contraction differences between instantiations).
+struct RopeRow { f32x4 c0, c1, c2, c3, s0, s1, s2, s3; };  // cos / sin of this thread's 8 + 8 dims at the row's sequence position
+
+G3_DEVICE RopeRow load_rope_row(const float* cos_t, const float* sin_t, int64_t spos, int sl) {
+    const float* cr = cos_t + spos * 128;
+    const float* sr = sin_t + spos * 128;
+    RopeRow t;
+    t.c0 = *reinterpret_cast<const f32x4*>(cr + sl * 8);
+    t.c1 = *reinterpret_cast<const f32x4*>(cr + sl * 8 + 4);
+    t.c2 = *reinterpret_cast<const f32x4*>(cr + 64 + sl * 8);
+    t.c3 = *reinterpret_cast<const f32x4*>(cr + 64 + sl * 8 + 4);
+    t.s0 = *reinterpret_cast<const f32x4*>(sr + sl * 8);
+    t.s1 = *reinterpret_cast<const f32x4*>(sr + sl * 8 + 4);
+    t.s2 = *reinterpret_cast<const f32x4*>(sr + 64 + sl * 8);
+    t.s3 = *reinterpret_cast<const f32x4*>(sr + 64 + sl * 8 + 4);
+    return t;
+}
+
+template <bool ROPE>
+G3_DEVICE void rmsnorm_rope_head(const bf16x8& a, const bf16x8& b, const bf16x8& wa, const bf16x8& wb, const RopeRow& t, float eps, bf16x8& oa, bf16x8& ob) {
+    float fa[8], fb[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        fa[e] = (float)a[e]; fb[e] = (float)b[e];
+        ss += fa[e] * fa[e] + fb[e] * fb[e];
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    ss += __shfl_xor(ss, 4, 64);
+    const float rinv = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    // round the normalised value to bf16 exactly where the reference does (RMSNorm output dtype)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        fa[e] = (float)f32_to_bf16(fa[e] * rinv * (float)wa[e]);
+        fb[e] = (float)f32_to_bf16(fb[e] * rinv * (float)wb[e]);
+    }
+    if (ROPE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ca = e < 4 ? t.c0[e & 3] : t.c1[e & 3];
+            const float cb = e < 4 ? t.c2[e & 3] : t.c3[e & 3];
+            const float sa = e < 4 ? t.s0[e & 3] : t.s1[e & 3];
+            const float sb = e < 4 ? t.s2[e & 3] : t.s3[e & 3];
+            oa[e] = f32_to_bf16(fa[e] * ca - fb[e] * sa);  // first half: t*cos + (-t2)*sin
+            ob[e] = f32_to_bf16(fb[e] * cb + fa[e] * sb);  // second half: t2*cos + t1*sin
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { oa[e] = f32_to_bf16(fa[e]); ob[e] = f32_to_bf16(fb[e]); }
+    }
+}
+
+// `in` and `out` are NOT __restrict__: the DiT runs these kernels IN PLACE on the q | k columns of the fused QKV buffer (out == in,
 // gen3c_amd/dit.py). That is sound because a thread reads exactly the 16 elements it later writes (its own 8-element slices of the two
-// rotary halves; the rotate-half partner b[] is this thread's own second slice) and all of its loads precede its stores - an invariant
+// rotary halves; the rotate-half partner b[] is this thread's own second slice) and all of a head's loads precede its stores - an invariant
 // of this body, kept visible to the compiler by leaving the two pointers possibly-aliasing.
+// (general form: any H; one 8-lane group per (row, head) - every group re-reads its row's 1 KiB of cos / sin and the weights)
 __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(const bf16_t* in, int64_t ld_in,
                                                               const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t,
@@ -156,53 +211,61 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(const bf16_t* in, 
     const bf16_t* src = in + row * ld_in + head * 128;
     const bf16x8 a = load_bf16x8(src + sl * 8);
     const bf16x8 b = load_bf16x8(src + 64 + sl * 8);
-    float fa[8], fb[8];
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        fa[e] = (float)a[e]; fb[e] = (float)b[e];
-        ss += fa[e] * fa[e] + fb[e] * fb[e];
-    }
-    ss += __shfl_xor(ss, 1, 64);
-    ss += __shfl_xor(ss, 2, 64);
-    ss += __shfl_xor(ss, 4, 64);
-    const float rinv = rsqrtf(ss * (1.0f / 128.0f) + eps);
     const bf16x8 wa = load_bf16x8(w + sl * 8);
     const bf16x8 wb = load_bf16x8(w + 64 + sl * 8);
-    // round the normalised value to bf16 exactly where the reference does (RMSNorm output dtype)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        fa[e] = (float)f32_to_bf16(fa[e] * rinv * (float)wa[e]);
-        fb[e] = (float)f32_to_bf16(fb[e] * rinv * (float)wb[e]);
-    }
     bf16x8 oa, ob;
     if (cos_t != nullptr) {
-        const float* cr = cos_t + spos * 128;
-        const float* sr = sin_t + spos * 128;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr + sl * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cr + sl * 8 + 4);
-        const f32x4 c2 = *reinterpret_cast<const f32x4*>(cr + 64 + sl * 8);
-        const f32x4 c3 = *reinterpret_cast<const f32x4*>(cr + 64 + sl * 8 + 4);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr + sl * 8);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sr + sl * 8 + 4);
-        const f32x4 s2 = *reinterpret_cast<const f32x4*>(sr + 64 + sl * 8);
-        const f32x4 s3 = *reinterpret_cast<const f32x4*>(sr + 64 + sl * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float ca = e < 4 ? c0[e & 3] : c1[e & 3];
-            const float cb = e < 4 ? c2[e & 3] : c3[e & 3];
-            const float sa = e < 4 ? s0[e & 3] : s1[e & 3];
-            const float sb = e < 4 ? s2[e & 3] : s3[e & 3];
-            oa[e] = f32_to_bf16(fa[e] * ca - fb[e] * sa);  // first half: t*cos + (-t2)*sin
-            ob[e] = f32_to_bf16(fb[e] * cb + fa[e] * sb);  // second half: t2*cos + t1*sin
-        }
+        const RopeRow t = load_rope_row(cos_t, sin_t, spos, sl);
+        rmsnorm_rope_head<true>(a, b, wa, wb, t, eps, oa, ob);
     } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { oa[e] = f32_to_bf16(fa[e]); ob[e] = f32_to_bf16(fb[e]); }
+        RopeRow t{};
+        rmsnorm_rope_head<false>(a, b, wa, wb, t, eps, oa, ob);
     }
     bf16_t* dst = out + row * ld_out + head * 128;
     store_bf16x8(dst + sl * 8, oa);
     store_bf16x8(dst + 64 + sl * 8, ob);
+}
+
+// Octet form (round 6): one 8-lane group owns 8 CONSECUTIVE heads of a row (2 KiB contiguous) and keeps the row's cos / sin (32 registers) and the
+// norm weights (8 registers) for all of them. The general form above moves 128 B of table + 32 B of weights through the vector memory path for every
+// 32 B of payload read - it ran at 3.7 TB/s of payload (28.3 ms of a 3.3 s step); here the table costs 16 B per 32 B. Two weight regions
+// (heads [0, h_a) with w_a, heads [h_a, h_a + h_b) with w_b: q and k of the fused QKV buffer normalised by ONE launch); h_a, h_b multiples of 8 so an
+// octet never straddles them. Same arithmetic body -> bitwise equal to the general form (tests/test_kernels_gpu.py).
+template <bool ROPE>
+__global__ __launch_bounds__(256) void qk_rmsnorm_rope_octet_kernel(const bf16_t* in, int64_t ld_in, const bf16_t* __restrict__ w_a, int h_a,
+                                                                    const bf16_t* __restrict__ w_b, int h_b, const float* __restrict__ cos_t,
+                                                                    const float* __restrict__ sin_t, bf16_t* out, int64_t ld_out, int64_t rows, int B,
+                                                                    float eps) {
+    const int sl = threadIdx.x & 7;
+    const int noct = (h_a + h_b) >> 3;
+    const int64_t gid = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);  // (row, octet), octet fastest: a wave's 8 groups walk 16 KiB of one or two rows
+    const int64_t row = gid / noct;
+    if (row >= rows) return;
+    const int oct = (int)(gid - row * noct);
+    const int head0 = oct * 8;
+    const bf16_t* w = head0 < h_a ? w_a : w_b;
+    const bf16x8 wa = load_bf16x8(w + sl * 8);
+    const bf16x8 wb = load_bf16x8(w + 64 + sl * 8);
+    RopeRow t{};
+    if (ROPE) t = load_rope_row(cos_t, sin_t, row / B, sl);
+    const bf16_t* src = in + row * ld_in + head0 * 128 + sl * 8;
+    bf16_t* dst = out + row * ld_out + head0 * 128 + sl * 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // 4 heads' loads in flight, then their stores (in place: a head's loads precede its own stores)
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            a[hh] = load_bf16x8(src + (half * 4 + hh) * 128);
+            b[hh] = load_bf16x8(src + (half * 4 + hh) * 128 + 64);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            bf16x8 oa, ob;
+            rmsnorm_rope_head<ROPE>(a[hh], b[hh], wa, wb, t, eps, oa, ob);
+            store_bf16x8(dst + (half * 4 + hh) * 128, oa);
+            store_bf16x8(dst + (half * 4 + hh) * 128 + 64, ob);
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -348,19 +411,50 @@ extern "C" int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const voi
     return g3_check_launch("g3_posemb_layernorm_modulate_bf16");
 }
 
+static int qk_rmsnorm_rope_launch(const char* what, const void* in, int64_t ld_in, const void* w_a, int h_a, const void* w_b, int h_b, const float* cos_table,
+                                  const float* sin_table, void* out, int64_t ld_out, int S, int B, int head_dim, float eps, void* stream) {
+    if (!in || !w_a || !out || (h_b > 0 && !w_b)) return g3_set_error(G3_ERR_ARG, "%s: null operand", what);
+    if (head_dim != 128) return g3_set_error(G3_ERR_ARG, "%s: head_dim must be 128", what);
+    if ((cos_table == nullptr) != (sin_table == nullptr)) return g3_set_error(G3_ERR_ARG, "%s: need both cos and sin tables or neither", what);
+    if ((ld_in & 7) || (ld_out & 7)) return g3_set_error(G3_ERR_ARG, "%s: leading dims must be multiples of 8", what);
+    if (S <= 0 || B <= 0 || h_a <= 0 || h_b < 0) return g3_set_error(G3_ERR_ARG, "%s: bad shape", what);
+    const int64_t rows = (int64_t)S * B;
+    if (g3_opt_norm_octets && (h_a % 8) == 0 && (h_b % 8) == 0) {
+        const int64_t ngroups = rows * ((h_a + h_b) >> 3);
+        const int64_t nblk = (ngroups + 31) / 32;
+        if (nblk > 0x7fffffff) return g3_set_error(G3_ERR_ARG, "%s: too many rows", what);
+        if (cos_table)
+            hipLaunchKernelGGL(qk_rmsnorm_rope_octet_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (const bf16_t*)w_a, h_a,
+                               (const bf16_t*)w_b, h_b, cos_table, sin_table, (bf16_t*)out, ld_out, rows, B, eps);
+        else
+            hipLaunchKernelGGL(qk_rmsnorm_rope_octet_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, (const bf16_t*)w_a, h_a,
+                               (const bf16_t*)w_b, h_b, cos_table, sin_table, (bf16_t*)out, ld_out, rows, B, eps);
+        return g3_check_launch(what);
+    }
+    // general form: one launch per weight region
+    for (int region = 0; region < (h_b > 0 ? 2 : 1); ++region) {
+        const int H = region ? h_b : h_a;
+        const int64_t col0 = region ? (int64_t)h_a * 128 : 0;
+        const int64_t n_pairs = rows * H;
+        const int64_t nblk = (n_pairs * 8 + 255) / 256;
+        hipLaunchKernelGGL(qk_rmsnorm_rope_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in + col0, ld_in,
+                           (const bf16_t*)(region ? w_b : w_a), cos_table, sin_table, (bf16_t*)out + col0, ld_out, n_pairs, H, B, eps);
+        const int rc = g3_check_launch(what);
+        if (rc) return rc;
+    }
+    return G3_OK;
+}
+
 extern "C" int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, const float* cos_table,
                                        const float* sin_table, void* out, int64_t ld_out, int S, int B, int H,
                                        int head_dim, float eps, void* stream) {
-    if (!in || !weight || !out) return g3_set_error(G3_ERR_ARG, "g3_qk_rmsnorm_rope_bf16: null operand");
-    if (head_dim != 128) return g3_set_error(G3_ERR_ARG, "g3_qk_rmsnorm_rope_bf16: head_dim must be 128");
-    if ((cos_table == nullptr) != (sin_table == nullptr)) return g3_set_error(G3_ERR_ARG, "g3_qk_rmsnorm_rope_bf16: need both cos and sin tables or neither");
-    if ((ld_in & 7) || (ld_out & 7)) return g3_set_error(G3_ERR_ARG, "g3_qk_rmsnorm_rope_bf16: leading dims must be multiples of 8");
-    const int64_t n_pairs = (int64_t)S * B * H;
-    const int64_t nthreads = n_pairs * 8;
-    const int64_t nblk = (nthreads + 255) / 256;
-    hipLaunchKernelGGL(qk_rmsnorm_rope_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
-                       ld_in, (const bf16_t*)weight, cos_table, sin_table, (bf16_t*)out, ld_out, n_pairs, H, B, eps);
-    return g3_check_launch("g3_qk_rmsnorm_rope_bf16");
+    return qk_rmsnorm_rope_launch("g3_qk_rmsnorm_rope_bf16", in, ld_in, weight, H, nullptr, 0, cos_table, sin_table, out, ld_out, S, B, head_dim, eps, stream);
+}
+
+extern "C" int g3_qk_rmsnorm_rope_pair_bf16(const void* in, int64_t ld_in, const void* weight_q, int H_q, const void* weight_k, int H_k, const float* cos_table,
+                                            const float* sin_table, void* out, int64_t ld_out, int S, int B, int head_dim, float eps, void* stream) {
+    if (H_k <= 0) return g3_set_error(G3_ERR_ARG, "g3_qk_rmsnorm_rope_pair_bf16: H_k must be positive (one region: g3_qk_rmsnorm_rope_bf16)");
+    return qk_rmsnorm_rope_launch("g3_qk_rmsnorm_rope_pair_bf16", in, ld_in, weight_q, H_q, weight_k, H_k, cos_table, sin_table, out, ld_out, S, B, head_dim, eps, stream);
 }
 
 extern "C" int g3_transpose_v_bf16(const void* v, int64_t ld_in, void* vt, int64_t ldvt, int S, int B, int H,

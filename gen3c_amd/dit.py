@@ -31,15 +31,24 @@ from .parallel import ContextParallelAttention, split_inputs_cp
 _FUSE_QKV_EPILOGUE = __import__("os").environ.get("G3_FUSE_QKV_EPILOGUE", "0") != "0"
 
 
+# 1 (default, round 6): the V third of the self-attention QKV projection is computed with the operands SWAPPED - V^T[b] = W_v . h[:, b]^T, one GEMM per batch item whose
+# "token" operand is the weight and whose output rows are the 128 H value features - so it lands directly in the V^T [B, H, 128, S] layout the attention kernel reads and
+# the separate transpose pass (g3_transpose_v_bf16: 10.7 ms of a 3.3 s step at 2.4 TB/s) disappears. Same products, same K order per element: bitwise equal to the
+# transpose of the fused projection's v columns (tests/test_kernels_gpu.py). 0: fused [S*B, 3D] projection + transpose (A/B).
+_V_OPERAND_SWAP = __import__("os").environ.get("G3_V_OPERAND_SWAP", "1") != "0"
+
+
 def _project_norm_rope(h, w, n_q, n_k, norm_q, norm_k, cos, sin, S, B, nH_total):
     """a @ w^T with per-head RMSNorm (+ RoPE) on the first n_q (weight norm_q) and the next n_k (norm_k) output features; the rest plain.
     Same rounding points either way (tested): the fused GEMM epilogue, or the plain GEMM followed by the in-place norm passes."""
     if _FUSE_QKV_EPILOGUE:
         return ops.gemm_qk_norm_rope(h, w, n_q, n_k, norm_q, norm_k, cos, sin, S, B)
     y = ops.gemm_nt(h, w)
-    if n_q:
+    if n_q and n_k:
+        ops.qk_rmsnorm_rope_pair(y[:, :n_q + n_k], norm_q, n_q // 128, norm_k, n_k // 128, cos, sin, S, B)
+    elif n_q:
         ops.qk_rmsnorm_rope(y[:, :n_q], norm_q, cos, sin, S, B, n_q // 128, out=y[:, :n_q])
-    if n_k:
+    elif n_k:
         ops.qk_rmsnorm_rope(y[:, n_q:n_q + n_k], norm_k, cos, sin, S, B, n_k // 128, out=y[:, n_q:n_q + n_k])
     return y
 
@@ -460,7 +469,15 @@ class VideoExtendGeneralDIT(nn.Module):
                 pos["full"] = (pe_sum / pos["norm"].reshape(Tp, Hp, Wp, 1)).reshape(S, D).contiguous()
                 del pe_sum
             h = ops.posemb_layernorm_modulate(xs, pos["full"], None, None, None, Tp, Hp, Wp, B, shift, scale)
-            if self._cp_attn is not None:
+            if self._cp_attn is not None and self._cp_attn.schedule == "local_first":
+                # local_first starts every head group on this rank's OWN K / V shard, so nothing waits for the exchange at first: one fused QKV
+                # projection + one norm / RoPE pass over q | k, then the exchange goes out under the local attention. At the cp = 8 shape
+                # (M = 14 080) a separate N = 4096 Q projection is 3.44 rounds of 256 x 256 tiles on 256 workgroups and ran at 77 % of its cp = 1
+                # rate (profiles/r6_cp_rank_shapes.txt); inside the N = 12 288 projection the same tiles are part of 10.3 rounds.
+                qkv = _project_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B, nH)
+                pending = self._cp_attn.start(qkv[:, D:2 * D], qkv[:, 2 * D:], S, B, nH)
+                o = self._cp_attn.finish(qkv[:, :D], pending)
+            elif self._cp_attn is not None:
                 # K / V first, so their exchange is in flight while Q is still being projected (same fused weight, sliced;
                 # every output element sees the same K order, so this is bit-identical to the single fused GEMM)
                 # the per-head RMSNorm + RoPE of q and k (attention.py:262-280) run in the projections' epilogues
@@ -474,10 +491,19 @@ class VideoExtendGeneralDIT(nn.Module):
                     vt = self._vt_buffer(S, B, nH, dev)
                     qkv = ops.gemm_qk_norm_rope(h, blk["fa_qkv"], D, D, blk["fa_qn"], blk["fa_kn"], cos, sin, S, B, vt=vt)
                     q, k = qkv[:, :D], qkv[:, D:2 * D]
-                else:  # plain GEMM, then q / k normalised + rotated IN PLACE in the fused buffer and v transposed (the default: see _FUSE_QKV_EPILOGUE)
+                elif _V_OPERAND_SWAP:
+                    # q | k: plain GEMM, then normalised + rotated IN PLACE by one pass; v: projected straight into V^T (operands swapped, see _V_OPERAND_SWAP)
+                    qk = ops.gemm_nt(h, blk["fa_qkv"][:2 * D])
+                    ops.qk_rmsnorm_rope_pair(qk, blk["fa_qn"], nH, blk["fa_kn"], nH, cos, sin, S, B)
+                    q, k = qk[:, :D], qk[:, D:]
+                    vt = self._vt_buffer(S, B, nH, dev)
+                    hv = h.view(S, B, D)
+                    for b_ in range(B):
+                        ops.gemm_nt(blk["fa_qkv"][2 * D:], hv[:, b_], out=vt[b_].view(D, -1)[:, :S])
+                else:  # plain GEMM, then q / k normalised + rotated IN PLACE in the fused buffer and v transposed
                     qkv = ops.gemm_nt(h, blk["fa_qkv"])
-                    q = ops.qk_rmsnorm_rope(qkv[:, :D], blk["fa_qn"], cos, sin, S, B, nH, out=qkv[:, :D])
-                    k = ops.qk_rmsnorm_rope(qkv[:, D:2 * D], blk["fa_kn"], cos, sin, S, B, nH, out=qkv[:, D:2 * D])
+                    ops.qk_rmsnorm_rope_pair(qkv[:, :2 * D], blk["fa_qn"], nH, blk["fa_kn"], nH, cos, sin, S, B)  # one pass over q | k
+                    q, k = qkv[:, :D], qkv[:, D:2 * D]
                     vt = ops.transpose_v(qkv[:, 2 * D:], S, B, nH, out=self._vt_buffer(S, B, nH, dev))
                 o = ops.flash_attn(q, k, vt, S, S, B, nH)
             ops.gemm_nt(o, blk["fa_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)

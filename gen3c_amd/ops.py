@@ -161,6 +161,24 @@ def qk_rmsnorm_rope(x: torch.Tensor, weight: torch.Tensor, cos: Optional[torch.T
     return out
 
 
+def qk_rmsnorm_rope_pair(x: torch.Tensor, weight_q: torch.Tensor, H_q: int, weight_k: torch.Tensor, H_k: int, cos: Optional[torch.Tensor],
+                         sin: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    """x: [S*B, (H_q + H_k)*128] view: heads [0, H_q) normalised with weight_q, the next H_k with weight_k, RoPE on all of them - q | k of the fused QKV
+    buffer in ONE launch (g3_qk_rmsnorm_rope_pair_bf16). out=None: in place."""
+    rows, width, ld_in = _rowmajor2d(x, "x")
+    assert rows == S * B and width == (H_q + H_k) * 128
+    if out is None:
+        out = x
+    cp = sp = 0
+    if cos is not None:
+        assert cos.shape == (S, 128) and sin.shape == (S, 128) and cos.is_contiguous() and sin.is_contiguous()
+        cp, sp = _dev(cos, "cos", torch.float32), _dev(sin, "sin", torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.g3_qk_rmsnorm_rope_pair_bf16(_dev(x, "x"), ld_in, _dev(weight_q, "weight_q"), H_q, _dev(weight_k, "weight_k"), H_k, cp, sp, _dev(out, "out"),
+                                                out.stride(0), S, B, 128, eps, _stream()), "g3_qk_rmsnorm_rope_pair_bf16")
+    return out
+
+
 def gemm_qk_norm_rope(a: torch.Tensor, w: torch.Tensor, n_q: int, n_k: int, norm_q: Optional[torch.Tensor], norm_k: Optional[torch.Tensor],
                       cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], S: int, B: int, out: Optional[torch.Tensor] = None,
                       eps: float = 1e-6, vt: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -129,6 +129,13 @@ int g3_qk_rmsnorm_rope_bf16(const void* in, int64_t ld_in, const void* weight, c
                             const float* sin_table, void* out, int64_t ld_out, int S, int B, int H, int head_dim,
                             float eps, void* stream);
 
+/* The same pass over TWO adjacent head ranges with their own norm weights in one launch: heads [0, H_q) of a row with weight_q, heads
+ * [H_q, H_q + H_k) with weight_k - q and k of the fused QKV buffer as Attention.cal_qkv normalises and rotates them (attention.py:262-280:
+ * to_q[1] / to_k[1] then apply_rotary_pos_emb on both). in / out: [S*B][(H_q + H_k) * 128] views (out may alias in). */
+int g3_qk_rmsnorm_rope_pair_bf16(const void* in, int64_t ld_in, const void* weight_q, int H_q, const void* weight_k, int H_k,
+                                 const float* cos_table, const float* sin_table, void* out, int64_t ld_out, int S, int B, int head_dim,
+                                 float eps, void* stream);
+
 /* Q / K(/V) projection with that per-head RMSNorm (+ RoPE) in the GEMM's epilogue (Attention.cal_qkv, attention.py:247-280, as one call):
  *   C[:, 0:n_q] = rope(rmsnorm(A W^T, norm_q)),  C[:, n_q:n_q+n_k] = rope(rmsnorm(A W^T, norm_k)),  C[:, n_q+n_k:N] = A W^T (e.g. v).
  * Row m is token (s = m / B, b = m % B); n_q, n_k, N multiples of 128 (whole heads); cos / sin fp32 [M/B][128] or both NULL. Same

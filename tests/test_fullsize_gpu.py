@@ -99,8 +99,7 @@ def _bench_launch_operands(dev, H=32, B=2, seed=11, chain="default"):
     else:
         assert chain == "separate"
         qkv = ops.gemm_nt(h, w)
-        ops.qk_rmsnorm_rope(qkv[:, :Dm], nq, cos, sin, S, B, H, out=qkv[:, :Dm])
-        ops.qk_rmsnorm_rope(qkv[:, Dm:2 * Dm], nk, cos, sin, S, B, H, out=qkv[:, Dm:2 * Dm])
+        ops.qk_rmsnorm_rope_pair(qkv[:, :2 * Dm], nq, H, nk, H, cos, sin, S, B)
         ops.transpose_v(qkv[:, 2 * Dm:], S, B, H, out=vt)
     return dict(h=h, w=w, nq=nq, nk=nk, ang=ang, qkv=qkv, vt=vt, Dm=Dm, chain=chain)
 
@@ -146,7 +145,7 @@ def test_bench_qkv_epilogue_vs_fp32_norm_rope(chain):
     """Both forms of the QKV chain at the benchmark size (S = 56 320, B = 2, D = 4096) - "separate" = what the DiT forward runs by default (plain
     projection, in-place norm + RoPE passes over 2.77 GB of strided views, V transpose), "fused" = the opt-in epilogue - against an fp32 evaluation
     of Attention.cal_qkv (attention.py:247-280: Linear, per-head RMSNorm with weight, non-interleaved RoPE; v plain) on sampled rows, and against
-    each other: the two chains share every rounding point, so their outputs are bitwise equal."""
+    each other (same rounding points; the sum of squares is accumulated in another order)."""
     from gen3c_amd import dit
     from oracle import dit_oracle
     dev = torch.device("cuda:0")
@@ -172,9 +171,13 @@ def test_bench_qkv_epilogue_vs_fp32_norm_rope(chain):
         assert r < 4e-3, f"v^T (b={b}): rel-L2 {r:.3e}"
     if vt.shape[-1] > S:
         assert float(vt[:, :, :, S:].float().abs().max()) == 0.0  # the zero tail the attention kernel relies on
-    if chain == "fused":  # the two chains share every rounding point: bitwise equal at full size too (q | k columns and V^T)
+    if chain == "fused":
+        # the two chains share every rounding point; what differs is the fp32 summation order of a head's 128 squares (tests/test_kernels_gpu.py), so
+        # V^T is bitwise equal and q | k agree up to an occasional 1-ulp bf16 flip
         other = _bench_launch_operands(dev, H, B, seed=12, chain="separate")
-        assert torch.equal(other["qkv"][:, :2 * Dm], qkv[:, :2 * Dm]) and torch.equal(other["vt"], vt)
+        assert torch.equal(other["vt"], vt)
+        r = _rel_l2(other["qkv"][:, :2 * Dm], qkv[:, :2 * Dm])
+        assert r < 1e-3, f"fused vs separate chain: rel-L2 {r:.3e}"
 
 
 def test_dit_full_size_single_block_vs_fp32_oracle():

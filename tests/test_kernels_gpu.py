@@ -362,6 +362,71 @@ def test_qk_rmsnorm_rope(S, B, H, rope):
     torch.testing.assert_close(out.float(), ref, rtol=1.5 / 128, atol=2e-2)
 
 
+@pytest.mark.parametrize("S,B,H,K", [(512, 2, 4, 512), (1000, 2, 2, 256), (4096, 1, 8, 1024), (2048, 2, 16, 4096)])
+def test_v_projection_by_operand_swap_is_the_transposed_projection(S, B, H, K):
+    """Round 6 (gen3c_amd/dit.py: _V_OPERAND_SWAP): V^T[b] = W_v . h[:, b]^T - the V projection with the GEMM's operands swapped, one launch per batch item,
+    written straight into the V^T [B, H, 128, ld] buffer - is BITWISE the transpose pass applied to the fused projection's v columns (same products,
+    same K order per element), on shapes that run the deferred-epilogue kernel (2048 x 2 x 16 heads x K 4096), the plain one-wave kernel and ragged tiles."""
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(S + H + K)
+    D = H * 128
+    h = torch.randn(S * B, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3 * D, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    qkv = ops.gemm_nt(h, w)
+    ld = ops.ceil_to(S, 64)
+    ref = ops.transpose_v(qkv[:, 2 * D:], S, B, H, out=torch.zeros(B, H, 128, ld, device=dev, dtype=torch.bfloat16))
+    vt = torch.zeros(B, H, 128, ld, device=dev, dtype=torch.bfloat16)
+    hv = h.view(S, B, K)
+    for b in range(B):
+        ops.gemm_nt(w[2 * D:], hv[:, b], out=vt[b].view(D, ld)[:, :S])
+    torch.cuda.synchronize()
+    assert torch.equal(vt, ref)
+    qk = ops.gemm_nt(h, w[:2 * D])
+    assert torch.equal(qk, qkv[:, :2 * D]), "a row slice of the fused weight gives the same q | k columns"
+
+
+@pytest.mark.parametrize("S,B,Hq,Hk,rope", [(333, 2, 8, 8, True), (130, 1, 16, 8, True), (97, 2, 8, 24, False), (1000, 2, 32, 32, True)])
+def test_qk_rmsnorm_rope_octet_and_pair(S, B, Hq, Hk, rope):
+    """Round 6: the octet form (one 8-lane group keeps a row's cos / sin and the weights for 8 consecutive heads) and the two-region entry
+    g3_qk_rmsnorm_rope_pair_bf16 (q | k of the fused QKV buffer in one in-place launch): vs the fp32 oracle, and BITWISE equal to the general
+    one-group-per-head kernel run region by region (same arithmetic body). Row counts that leave ragged last workgroups."""
+    from gen3c_amd import _lib, ops
+    from oracle import dit_oracle
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(S + Hq + 3 * Hk)
+    Dq, Dk = Hq * 128, Hk * 128
+    qkv = torch.randn(S * B, Dq + Dk + 256, device=dev, generator=g).to(torch.bfloat16)  # a strided view with a plain tail (the v columns)
+    wq = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    wk = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    freqs = torch.randn(S, 128, device=dev, generator=g) * 3
+    cos, sin = (torch.cos(freqs).contiguous(), torch.sin(freqs).contiguous()) if rope else (None, None)
+    lib = _lib.load()
+    general = qkv.clone()
+    assert lib.g3_set_option(b"norm_octets", 0) == 0
+    try:
+        ops.qk_rmsnorm_rope(general[:, :Dq], wq, cos, sin, S, B, Hq, out=general[:, :Dq])
+        ops.qk_rmsnorm_rope(general[:, Dq:Dq + Dk], wk, cos, sin, S, B, Hk, out=general[:, Dq:Dq + Dk])
+    finally:
+        assert lib.g3_set_option(b"norm_octets", 1) == 0
+    octet = qkv.clone()
+    ops.qk_rmsnorm_rope(octet[:, :Dq], wq, cos, sin, S, B, Hq, out=octet[:, :Dq])
+    ops.qk_rmsnorm_rope(octet[:, Dq:Dq + Dk], wk, cos, sin, S, B, Hk, out=octet[:, Dq:Dq + Dk])
+    pair = qkv.clone()
+    ops.qk_rmsnorm_rope_pair(pair[:, :Dq + Dk], wq, Hq, wk, Hk, cos, sin, S, B)
+    separate = ops.qk_rmsnorm_rope(qkv[:, :Dq], wq, cos, sin, S, B, Hq)  # out of place, packed output
+    torch.cuda.synchronize()
+    assert torch.equal(octet, general), "octet form != general form"
+    assert torch.equal(pair, general), "two-region launch != two launches"
+    assert torch.equal(separate, general[:, :Dq])
+    assert torch.equal(pair[:, Dq + Dk:], qkv[:, Dq + Dk:]), "the plain tail must be untouched"
+    for x, w, H, got in ((qkv[:, :Dq], wq, Hq, pair[:, :Dq]), (qkv[:, Dq:Dq + Dk], wk, Hk, pair[:, Dq:Dq + Dk])):
+        ref = dit_oracle.te_rmsnorm(x.float().reshape(S, B, H, 128), w.float())
+        if rope:
+            ref = dit_oracle.te_rope_fused(ref, freqs.view(S, 1, 1, 128))
+        torch.testing.assert_close(got.float(), ref.reshape(S * B, H * 128), rtol=1.5 / 128, atol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1, 256, 4096, 1), (1, 12288, 256, 0), (3, 100, 64, 1), (8, 384, 128, 0)])
 def test_gemv(M, N, K, act):
     from gen3c_amd import ops

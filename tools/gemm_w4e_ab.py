@@ -1,6 +1,7 @@
 """A/B of build-time variants of the deferred-epilogue GEMM (csrc/gemm_w4e.hpp) at the benchmark shapes, interleaved in one process on one box.
 Build HERE before gpurun:  python tools/gemm_w4e_ab.py --build      (copies of the library with -DG3_AB_GW4E_PF=0 / 1, -DG3_GW4E_PFD=8)
 GPU box:                   python tools/gemm_w4e_ab.py
+Shapes: G3_W4E_AB_SHAPES="name:M:N:K:epilogue;..." (default: the four block GEMMs at M = 2 x 56 320).
 Variants (G3_W4E_AB_VARIANTS="name=flags;..."): product (no prefetch), pf1 (token slices by every workgroup), pf2 (token + weight slices), pf3 / pf4 (leaders only),
 and the product library with gemm_deferred = 0 (the non-persistent one-wave kernel)."""
 import ctypes as C
@@ -35,7 +36,10 @@ for suffix, _ in VARIANTS:
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 B = 2  # the benchmark's launches carry both CFG branches: M = 2 x 56 320
-for (nm, M, N, K, epi) in [("qkv", 56320 * B, 12288, 4096, 0), ("out", 56320 * B, 4096, 4096, 2), ("w1", 56320 * B, 16384, 4096, 1), ("w2", 56320 * B, 4096, 16384, 2)]:
+SHAPES = [("qkv", 56320 * B, 12288, 4096, 0), ("out", 56320 * B, 4096, 4096, 2), ("w1", 56320 * B, 16384, 4096, 1), ("w2", 56320 * B, 4096, 16384, 2)]
+if os.environ.get("G3_W4E_AB_SHAPES"):  # "name:M:N:K:epilogue;..." (e.g. the per-rank shapes of cp = 8: M = 14 080)
+    SHAPES = [(t.split(":")[0], *[int(x) for x in t.split(":")[1:]]) for t in os.environ["G3_W4E_AB_SHAPES"].split(";") if t]
+for (nm, M, N, K, epi) in SHAPES:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     gate = torch.randn(B, N, device=dev).to(torch.bfloat16)

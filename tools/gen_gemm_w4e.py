@@ -84,8 +84,10 @@ def dma_m0(q: int) -> Op:
     return Op(f"s_mov_b32 m0, %[m{q}]", "salu", tag=f"m0:{q}")
 
 
-def dma_ld(q: int) -> Op:
-    return Op(f"global_load_lds_dwordx4 %[vo{q}], %[sb{q}]", "vmem", tag=f"ld:{q}")
+def dma_ld(q: int, role: str = "") -> Op:
+    """role: "F" / "S" = the piece belongs to the first / second operand of the piece order (gemm_w4e.hpp: TF) - emitted with the cache-policy macro
+    GW4E_CPOL_<role> behind the instruction (A/B builds: non-temporal hint on one operand's stream; empty in the product)."""
+    return Op(f"global_load_lds_dwordx4 %[vo{q}], %[sb{q}]" + (f"@@{role}" if role else ""), "vmem", tag=f"ld:{q}")
 
 
 # base filler layout of a K step (gap -> ops), as tuned in gemm_w4.hpp: READ: the 8 fragment reads of the next K step (token fragments first: they were
@@ -99,11 +101,11 @@ def base_layout(ks: int, read: bool, np_: int) -> list[list[Op]]:
     if np_ == 5:
         for q, (gm, gl) in enumerate(((0, 1), (3, 4), (6, 7), (9, 10), (12, 13))):
             gaps[gm].append(dma_m0(q))
-            gaps[gl].append(dma_ld(q))
+            gaps[gl].append(dma_ld(q, ("F" if q < 2 else "S") if ks == 0 else "S"))  # K step 0: first operand's rows 6, 7 + second's 0..2; K step 1: second's 3..7
     elif np_ == 6:
         for q, (gm, gl) in enumerate(((0, 1), (3, 4), (5, 6), (8, 9), (11, 12), (13, 14))):
             gaps[gm].append(dma_m0(q))
-            gaps[gl].append(dma_ld(q))
+            gaps[gl].append(dma_ld(q, "F"))  # K step 3: the first operand's rows 0..5 of K tile t + 2
     elif np_ != 0:
         raise ValueError(np_)
     return gaps
@@ -337,6 +339,9 @@ def emit_fn(name: str, texts: list[str], comment: str = "") -> str:
         elif t.startswith("#"):
             _, cls, txt = t.split("#", 2)
             body.append(f'        GW4E_AB_{cls}("{txt}\\n\\t")')
+        elif "@@" in t:
+            txt, role = t.split("@@")
+            body.append(f'        "{txt}" GW4E_CPOL_{role} "\\n\\t"')
         else:
             body.append(f'        "{t}\\n\\t"')
     body.append("        : " + ", ".join(outs))
@@ -497,6 +502,22 @@ HEADER = '''// GENERATED by tools/gen_gemm_w4e.py - do not edit; tests/test_gemm
 #define GW4E_BARWAIT_0 "s_waitcnt vmcnt(1) lgkmcnt(0)\\n\\t"
 #define GW4E_BARWAIT_1 "s_waitcnt vmcnt(2) lgkmcnt(0)\\n\\t"
 #define GW4E_BARWAIT_2 "s_waitcnt vmcnt(3) lgkmcnt(0)\\n\\t"
+#endif
+
+// cache policy of the operand LDS-DMA pieces by role (first / second operand of the piece order): empty in the product. A/B builds (profiles/r6_mlp_down_ab.txt):
+// -DG3_AB_GW4E_CPOL=<bits>  1: non-temporal hint on the FIRST operand's pieces (the token stream where N <= 4096), 2: on the second's
+#ifndef G3_AB_GW4E_CPOL
+#define G3_AB_GW4E_CPOL 0
+#endif
+#if G3_AB_GW4E_CPOL & 1
+#define GW4E_CPOL_F " nt"
+#else
+#define GW4E_CPOL_F ""
+#endif
+#if G3_AB_GW4E_CPOL & 2
+#define GW4E_CPOL_S " nt"
+#else
+#define GW4E_CPOL_S ""
 #endif
 
 struct GW4EOps {
