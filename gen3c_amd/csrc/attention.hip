@@ -53,6 +53,12 @@ struct AttnParams {
     // softmax scale included); g3_attn_merge_partials_bf16 combines the parts of a row: softmax over the union of their keys.
     float* O32;
     float* LSE;
+    // zero-tail shortcut (v3 kernels; g3_flash_attn_fwd_ztail_bf16): 0 < kv_dense < Skv, a multiple of 64: the caller GUARANTEES that keys [kv_dense, Skv) have
+    // all-zero K rows AND all-zero V^T columns (zero-padded T5 tokens: to_k / to_v have no bias and RMSNorm(0) = 0). Their scores are exactly 0 and their values
+    // add nothing, so only the first kv_dense keys go through the tile loop and the epilogue adds the tail in closed form: m' = max(m, 0),
+    // l' = l 2^(m - m') + (Skv - kv_dense) 2^(-m'), O scaled by 2^(m - m') - the same softmax over all Skv keys (they stay in the denominator,
+    // general_dit.py:407-410). 0 = every key goes through the loop.
+    int kv_dense;
 };
 
 G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
@@ -521,6 +527,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     const int wave = tid >> 6;
     const int l31 = lane & 31;
     const int g = lane >> 5;
+    const int Skv = p.kv_dense > 0 ? p.kv_dense : p.Skv;  // keys that go through the tile loop (AttnParams::kv_dense: the rest is an all-zero tail)
     const int head = blockIdx.y;
     const int batch = blockIdx.z;
 
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     const uint32_t k_lane = (uint32_t)k_row0 * k_row_bytes + (uint32_t)k_src_chunk * 16u;   // + kv0 * k_row_bytes (+ 32 rows)
     const uint32_t v_lane0 = (uint32_t)v_row0 * (uint32_t)p.vt_row * 2u + (uint32_t)v_src_chunk * 16u;  // + kv0 * 2
     const uint32_t v_lane1 = v_lane0 + 64u * (uint32_t)p.vt_row * 2u;
-    const uint32_t k_last = (uint32_t)(p.Skv - 1) * k_row_bytes + (uint32_t)k_src_chunk * 16u;  // clamp target for ragged tails
+    const uint32_t k_last = (uint32_t)(Skv - 1) * k_row_bytes + (uint32_t)k_src_chunk * 16u;  // clamp target for ragged tails
     auto dma_k = [&](int kv0, int slot) {
         bf16_t* d = sK + slot * KVB * HD + wave * 64 * 8;
         uint32_t o0 = k_lane + (uint32_t)kv0 * k_row_bytes;
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
     float m_run = -1e30f;
     float l_run = 0.f;
     const float c = p.scale_log2;
-    const int nt = (p.Skv + KVB - 1) / KVB;
+    const int nt = (Skv + KVB - 1) / KVB;
 
     auto row_max = [&](const f32x16 (&S)[2]) -> float {  // two independent v_max3 chains (one per 32-kv block)
         if (G3_AB_ATTN_ABLATE & 4) return 0.f;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + 32 * mb + 16 * (r >> 3) + 8 * g + (r & 7);
-                if (kv >= p.Skv) S[mb][r] = -INFINITY;
+                if (kv >= Skv) S[mb][r] = -INFINITY;
             }
     };
 
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
 #ifndef G3_AB_OMIT_PROLOGUE_BARRIER  // (defined only to prove that tools/race_screen.py detects this race)
     __syncthreads();
 #endif
-    if (nt == 1 && KVB > p.Skv) mask_tail(SA, 0);
+    if (nt == 1 && KVB > Skv) mask_tail(SA, 0);
     float mx_cur = row_max(SA);
     f32x16 negm;  // FOLD: -m_run in every element: C operand of the first QK^T MFMA of a block, so scores arrive as s*c - m_run
     if (FOLD) {   // scores are kept RELATIVE to m_run from here on; the first tile fixes m_run to its exact maximum
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         constexpr int par = decltype(par_c)::value;
         const int kv0 = t * KVB;
         G3_JITTER(wave + blockIdx.x, t);
-        if (!has_next && kv0 + KVB > p.Skv) {  // ragged tile can only be the last one: redo its row max on masked scores
+        if (!has_next && kv0 + KVB > Skv) {  // ragged tile can only be the last one: redo its row max on masked scores
             mask_tail(S_cur, kv0);
             mx_cur = row_max(S_cur);
         }
@@ -868,8 +875,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         tile(SA, SB, t, False{}, P0{});
     }
 
-    const float l_tot = xor32_sum(l_run);
-    const float inv = 1.0f / l_tot;
+    float l_tot = xor32_sum(l_run);
+    float o_scale = 1.0f;
+    if (p.kv_dense > 0 && p.kv_dense < p.Skv) {  // the all-zero tail in closed form (wave-uniform branch): score 0 for each of its keys, nothing added to O
+        const float m_new = fmaxf(m_run, 0.f);
+        o_scale = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_tot = l_tot * o_scale + (float)(p.Skv - p.kv_dense) * __builtin_amdgcn_exp2f(-m_new);
+        m_run = m_new;
+    }
+    const float inv = o_scale / l_tot;
     if (p.O32) {  // split-KV part: fp32 normalised partial + log-sum-exp (wave-uniform branch, after the loop)
         if (q_ok) {
             float* orow = p.O32 + (int64_t)blockIdx.z * p.o_batch + (int64_t)blockIdx.y * p.o_head + (int64_t)q_idx * p.o_row;
@@ -942,7 +956,7 @@ extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) 
 static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
                              int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
                              int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H,
-                             int head_dim, float softmax_scale, void* stream, int variant_req = 0, float* o_partial = nullptr, float* lse = nullptr) {
+                             int head_dim, float softmax_scale, void* stream, int variant_req = 0, float* o_partial = nullptr, float* lse = nullptr, int kv_dense = 0) {
     if (!q || !k || !vt || (!o && !o_partial)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
     if ((o_partial != nullptr) != (lse != nullptr)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: o_partial and lse go together");
     if (o_partial && (((uintptr_t)o_partial & 15) || ((uintptr_t)lse & 3))) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: misaligned o_partial / lse");
@@ -967,6 +981,12 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.vt_seg_len = vt_seg_len; p.vt_seg_stride = vt_seg_stride;
     p.grid_q = 0; p.n_hb = 0; p.n_heads = H; p.xcd_heads = 0;
     p.O32 = o_partial; p.LSE = lse;
+    p.kv_dense = 0;
+    if (kv_dense > 0) {
+        const int kd = ((kv_dense + KVB - 1) / KVB) * KVB;  // whole tiles: the keys between kv_dense and the tile end are zero rows like the rest of the tail
+        if (kv_dense > Skv) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ztail_bf16: kv_dense %d > S_kv %d", kv_dense, Skv);
+        if (kd < Skv) p.kv_dense = kd;
+    }
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
@@ -975,6 +995,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b, 11 = w4b + cross-barrier prefetch.
     int variant = attn_resolve_variant(Sq, Skv, B, H, variant_req);
     if (o_partial && variant == 9) variant = 4;  // w4 (ragged S_kv) has no partial epilogue: the 8-wave kernel takes ragged tiles too
+    if (p.kv_dense && (variant < 3 || variant >= 9)) variant = 4;  // the zero-tail epilogue lives in the v3 kernels
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
         // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
@@ -1062,6 +1083,16 @@ extern "C" int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_
     if (vt_seg_len <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: vt_seg_len must be positive");
     return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, vt_seg_len, vt_seg_stride, o, o_row,
                              o_batch, o_head, Sq, Skv, B, H, head_dim, softmax_scale, stream);
+}
+
+/* ---- zero-tail shortcut (AttnParams::kv_dense): the caller guarantees all-zero K rows and V^T columns for keys [kv_dense, Skv) ------------------------------- */
+extern "C" int g3_flash_attn_fwd_ztail_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
+                                            int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, void* o, int64_t o_row,
+                                            int64_t o_batch, int64_t o_head, int Sq, int Skv, int kv_dense, int B, int H, int head_dim, float softmax_scale,
+                                            void* stream) {
+    if (kv_dense <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ztail_bf16: kv_dense must be positive (all keys dense: g3_flash_attn_fwd_bf16)");
+    return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, 0, 0, o, o_row, o_batch, o_head, Sq, Skv, B, H,
+                             head_dim, softmax_scale, stream, 0, nullptr, nullptr, kv_dense);
 }
 
 /* ---- per-call kernel choice + split-KV partial outputs ------------------------------------------------------------------------------------ */

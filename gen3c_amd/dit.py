@@ -170,6 +170,9 @@ class VideoExtendGeneralDIT(nn.Module):
         self.cp_group = None
         self.cp_size = None
         self._cp_attn: Optional[ContextParallelAttention] = None
+        # True (default): the cross-attention runs its tile loop over the non-zero context tokens only and takes the zero-padded tail in closed form
+        # (_cross_attention_kv); False: every context token goes through the loop (bench.py's timed region: the dense workload of BASELINE.json)
+        self.cross_attention_skip_zero_context = True
         self._tables: Dict[tuple, tuple] = {}
         self._packed = None
         self._tune_blocks: Optional[int] = None  # bench.py's context-parallel autotune: run only the first n blocks (not a model option)
@@ -311,7 +314,10 @@ class VideoExtendGeneralDIT(nn.Module):
         import torch.distributed as dist
         self.cp_group = cp_group
         self.cp_size = dist.get_world_size(cp_group)
-        self._cp_attn = ContextParallelAttention(cp_group)
+        # default schedule of the DiT: local_first, 4 head groups - on one GPU playing one rank (tools/cp_rank_emulate.py, profiles/r6_cp_rank_shapes.txt) it is the
+        # fastest or within 2 % of the fastest at cp = 2 / 4 / 8, it never waits for the first exchange, and with it the QKV projection stays ONE launch
+        # (forward()). The class default stays gather_first (bitwise equal to the single-rank attention).
+        self._cp_attn = ContextParallelAttention(cp_group, head_groups=4, schedule="local_first")
         # G3_CP_CONFIG="<head groups>,<auto|w4b|wave8>,<gather_first|local_first>": the configuration `python bench.py --gpus N` measured fastest on
         # this node (its `cp.chosen`), for the entry points that do not tune themselves (gen3c_single_image.py --num_gpus N, ...)
         cfg = __import__("os").environ.get("G3_CP_CONFIG")
@@ -460,7 +466,9 @@ class VideoExtendGeneralDIT(nn.Module):
         # ---- context
         M = crossattn_emb.shape[1]
         nH = self.num_heads
-        ca_kv = self._cross_attention_kv(pk, crossattn_emb)
+        ca_kv, ca_dense = self._cross_attention_kv(pk, crossattn_emb)
+        if not self.cross_attention_skip_zero_context:
+            ca_dense = 0
         for bi, blk in enumerate(pk["blocks"][: self._tune_blocks] if self._tune_blocks else pk["blocks"]):
             # -- self attention; "x = x + extra_per_block_pos_emb" (blocks.py:547-548) rides in the same pass over x as the LayerNorm
             shift, scale, gate = self._modulation(emb, blk["ada"][0], adaln_lora, 3)
@@ -512,7 +520,7 @@ class VideoExtendGeneralDIT(nn.Module):
             h = ops.layernorm_modulate(xs, shift, scale)
             q = _project_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B, nH)
             k, vt = ca_kv[bi]
-            o = ops.flash_attn(q, k, vt, S, M, B, nH)
+            o = ops.flash_attn(q, k, vt, S, M, B, nH, kv_dense=ca_dense)
             ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- MLP
             shift, scale, gate = self._modulation(emb, blk["ada"][2], adaln_lora, 3)
@@ -549,7 +557,7 @@ class VideoExtendGeneralDIT(nn.Module):
         cache = self.__dict__.setdefault("_ca_kv_cache", {})
         hit = cache.get(key) if use_cache else None
         if hit is not None and hit[0] is crossattn_emb:
-            return hit[1]
+            return hit[1], hit[2]
         B, M = crossattn_emb.shape[:2]
         D, nH = self.model_channels, self.num_heads
         ctx = crossattn_emb.to(torch.bfloat16).permute(1, 0, 2).reshape(M * B, -1).contiguous()  # rows (m, b)
@@ -558,11 +566,26 @@ class VideoExtendGeneralDIT(nn.Module):
             kv = ops.gemm_nt(ctx, blk["ca_kv"])  # [M*B, 2D]
             per_block.append((ops.qk_rmsnorm_rope(kv[:, :D], blk["ca_kn"], None, None, M, B, nH), ops.transpose_v(kv[:, D:], M, B, nH)))
         if not use_cache:
-            return per_block
+            return per_block, 0  # (no zero-tail detection without a cache entry to keep it in: it costs a host synchronisation)
+        # Zero-padded context (text_encoder pads the T5 embedding with zero rows to 512 tokens): to_k / to_v have no bias and RMSNorm(0) = 0, so the padding's K
+        # rows and V^T columns are exactly zero in every block. How many leading tokens carry anything is read ONCE per cached context (one host
+        # synchronisation, with the K / V^T tails VERIFIED to be zero on the device) and handed to the attention launch, which then runs its tile loop over
+        # those keys only and adds the tail in closed form (g3_flash_attn_fwd_ztail_bf16: the padded tokens stay in the softmax denominator exactly as
+        # general_dit.py:407-410 has them). A context without a zero tail, or any non-zero found in a tail, gives 0 = every key through the loop.
+        dense = 0
+        live = (crossattn_emb != 0).any(dim=-1).any(dim=0)  # [M]: token m is non-zero for some batch item
+        n_live = int(live.nonzero().max()) + 1 if bool(live.any()) else 1
+        cand = min(M, ops.ceil_to(n_live, 64))
+        if cand < M:
+            dirty = torch.zeros((), dtype=torch.bool, device=crossattn_emb.device)
+            for k_, vt_ in per_block:
+                dirty |= (k_[cand * B:] != 0).any() | (vt_[..., cand:M] != 0).any()
+            if not bool(dirty):
+                dense = cand
         while len(cache) >= 4:  # cond / uncond (+ one spare pair): bounded, oldest first
             cache.pop(next(iter(cache)))
-        cache[key] = (crossattn_emb, per_block)  # holding the tensor keeps its storage (hence the address in the key) alive
-        return per_block
+        cache[key] = (crossattn_emb, per_block, dense)  # holding the tensor keeps its storage (hence the address in the key) alive
+        return per_block, dense
 
     def _modulation(self, emb, ada, lora, n):
         """(shift, scale[, gate]) = chunk_n( W2 . (W1 . SiLU(emb)) + adaln_lora )   (blocks.py:442-447)"""

@@ -148,6 +148,38 @@ def test_cross_attention_kv_cache_follows_context_and_weights():
     assert len(net._ca_kv_cache) <= 4
 
 
+def test_cross_attention_zero_padded_context_shortcut_matches_dense():
+    """Round 6: a context whose tokens beyond the prompt are zero rows (how text_encoder pads T5 embeddings to 512) is detected once per cached context
+    and the cross-attention then loops over the live keys only (g3_flash_attn_fwd_ztail_bf16) - the forward must equal the one with the shortcut switched
+    off (every key through the loop) up to the summation order of the identical tail terms; a context WITHOUT a zero tail must not take the shortcut."""
+    from gen3c_amd.dit import VideoExtendGeneralDIT
+    dev = torch.device("cuda:0")
+    net = VideoExtendGeneralDIT(max_img_h=48, max_img_w=48, max_frames=16, in_channels=81, model_channels=256, num_blocks=2, num_heads=2,
+                                adaln_lora_dim=32, crossattn_emb_channels=128, rope_t_extrapolation_ratio=2.0, device=dev, init_weights=False)
+    net.initialize_weights(randomize_adaln=True, seed=3)
+    B, T, H, W, M = 2, 2, 16, 16, 512
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
+    x, pose, ctx = rnd(B, 16, T, H, W), rnd(B, 64, T, H, W), rnd(B, M, 128)
+    ctx[0, 70:] = 0
+    ctx[1, 40:] = 0  # batch items with different prompt lengths: the longer one decides (70 -> 128 keys through the loop)
+    mask = torch.zeros(B, 1, T, H, W, device=dev, dtype=torch.bfloat16)
+    kw = dict(x=x, timesteps=torch.tensor([0.5, 0.5], device=dev, dtype=torch.bfloat16), crossattn_mask=None, fps=torch.tensor([24.0], device=dev),
+              padding_mask=torch.zeros(B, 1, 8 * H, 8 * W, device=dev, dtype=torch.bfloat16), condition_video_indicator=mask[:, :, :, :1, :1],
+              condition_video_input_mask=mask, condition_video_pose=pose)
+    y_short = net(crossattn_emb=ctx, **kw)
+    assert [v[2] for v in net._ca_kv_cache.values()] == [128]
+    net.cross_attention_skip_zero_context = False
+    y_dense = net(crossattn_emb=ctx, **kw)
+    net.cross_attention_skip_zero_context = True
+    rel = float((y_short.float() - y_dense.float()).norm() / y_dense.float().norm())
+    print(f"[dit zero-padded context 70/512 live] shortcut vs dense rel_l2={rel:.3e}")
+    assert torch.isfinite(y_short.float()).all() and rel < 2e-3
+    full = rnd(B, M, 128)
+    y_full = net(crossattn_emb=full, **kw)
+    assert [v[2] for v in net._ca_kv_cache.values()] == [128, 0] and torch.isfinite(y_full.float()).all()
+
+
 def test_dit_forward_under_inference_mode_matches_no_grad():
     """forward() must run when the caller wraps it in torch.inference_mode() (the reference's pipelines do) - weights created
     under it, context tensor created under it - and give the bits of the no_grad call."""

@@ -362,6 +362,42 @@ def test_qk_rmsnorm_rope(S, B, H, rope):
     torch.testing.assert_close(out.float(), ref, rtol=1.5 / 128, atol=2e-2)
 
 
+@pytest.mark.parametrize("Sq,Skv,live,B,H", [(700, 512, 64, 2, 4), (512, 512, 100, 1, 2), (1000, 512, 300, 2, 2), (300, 256, 1, 2, 3), (513, 512, 449, 1, 2)])
+def test_flash_attn_zero_tail_is_the_dense_softmax(Sq, Skv, live, B, H):
+    """Round 6 (g3_flash_attn_fwd_ztail_bf16): keys [live, Skv) have all-zero K rows and V^T columns (zero-padded T5 tokens). The launch that runs its tile
+    loop over ceil64(live) keys and adds the tail in closed form must give the softmax over ALL Skv keys - the padded tokens stay in the denominator
+    (general_dit.py:407-410) - i.e. what the dense launch gives (same kernel, other summation order of the identical tail terms: <= 1 bf16 ulp apart) and
+    what an fp32 softmax over all keys gives. Cases: scores well below and well above 0 (the tail's score) so that both branches of m' = max(m, 0) run;
+    live = 449 -> ceil64 = 512 = Skv: nothing to skip (plain launch)."""
+    from gen3c_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Sq + live)
+    for qscale in (0.3, 3.0):
+        q = (torch.randn(Sq * B, H * 128, device=dev, generator=g) * qscale).to(torch.bfloat16)
+        k = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+        v = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+        k[live * B:] = 0
+        v[live * B:] = 0
+        vt = ops.transpose_v(v, Skv, B, H)
+        dense = ops.flash_attn(q, k, vt, Sq, Skv, B, H)
+        short = ops.flash_attn(q, k, vt, Sq, Skv, B, H, kv_dense=live)
+        torch.cuda.synchronize()
+        qf = q.float().view(Sq, B, H, 128).permute(1, 2, 0, 3)
+        kf = k.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+        vf = v.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+        ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(128), dim=-1) @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
+        r_d, r_s = _rel_l2(dense, ref), _rel_l2(short, ref)
+        r_ds = _rel_l2(short, dense)
+        print(f"[zero tail Sq{Sq} Skv{Skv} live{live} B{B} H{H} qscale {qscale}] dense vs fp32 {r_d:.2e}  shortcut vs fp32 {r_s:.2e}  shortcut vs dense {r_ds:.2e}")
+        assert r_s < 6e-3 and r_s <= 1.2 * r_d + 1e-4
+        assert r_ds < 2e-3
+        # all-negative scores (every real key scores below the tail's 0): the tail dominates the denominator
+        q2 = (-(k.float()[:B].repeat(Sq, 1)) * 0.5).to(torch.bfloat16)
+        d2 = ops.flash_attn(q2, k, vt, Sq, Skv, B, H)
+        s2 = ops.flash_attn(q2, k, vt, Sq, Skv, B, H, kv_dense=live)
+        assert _rel_l2(s2, d2) < 2e-3
+
+
 @pytest.mark.parametrize("S,B,H,K", [(512, 2, 4, 512), (1000, 2, 2, 256), (4096, 1, 8, 1024), (2048, 2, 16, 4096)])
 def test_v_projection_by_operand_swap_is_the_transposed_projection(S, B, H, K):
     """Round 6 (gen3c_amd/dit.py: _V_OPERAND_SWAP): V^T[b] = W_v . h[:, b]^T - the V projection with the GEMM's operands swapped, one launch per batch item,

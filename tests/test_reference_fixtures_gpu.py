@@ -53,8 +53,18 @@ def test_render_cache_on_reference_image_vs_oracle(fg):
     torch.cuda.synchronize()
     assert pix.shape == (1, 2, 1, 3, h, w) and msk.shape == (1, 2, 1, 1, h, w)
 
-    pts = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    # The oracle warps the PRODUCT's cache points (its unprojection kernel, held here against the oracle's to 2e-6): the reference's splat gives a pixel whose
+    # projected coordinate is EXACTLY an integer twice the weight of one a single ulp beside it (floor == ceil: both corner pairs hit the same texel with weight 1,
+    # forward_warp_utils_pytorch.py:604-634), and under this scene's first camera (pure x translation) v lands on integers up to rounding - so two unprojections
+    # that differ by one ulp (the reference's own matmul order is not fixed across devices either) flip that factor 2 pixel by pixel. On smooth synthetic images
+    # it cannot be seen; between neighbours of a natural image it moved 735 of 5.4 M colour values by up to 0.19 (profiles/r6_render_fixture_diag.txt: every
+    # form of the renderer, the plain global-atomics one included, gave the identical 735; the oracle's fp32 sums equal fp64 sums). Same points -> bit-exact flow.
+    pts_o = wo.unproject_points(depth[None, None], np.eye(4, dtype=np.float32)[None], K[None])
+    pts = renderer.unproject_points(_t(depth, dev)[None, None], torch.eye(4, device=dev)[None], _t(K, dev)[None]).cpu().numpy()
+    np.testing.assert_allclose(pts, pts_o, rtol=0, atol=2e-6)
     rel = wo.reliable_depth_mask(depth[None, None], ratio_thresh=0.05).astype(np.float32)
+    rel_p = renderer.reliable_depth_mask_range_batch(_t(depth, dev)[None, None], ratio_thresh=0.05)[0, 0].cpu().numpy()
+    assert np.array_equal(rel_p, rel[0, 0] > 0), "reliable-depth mask of the cache != oracle"
     bnd = ~wo.reliable_depth_mask(depth[None, None])[0, 0]
     assert 0.5 < rel.mean() < 0.97 and bnd.sum() > 20000, "the image's depth layers must leave ragged, long boundaries"
     b2 = lambda a: np.broadcast_to(a, (2,) + a.shape[1:])

@@ -68,3 +68,49 @@ rel_p = renderer.reliable_depth_mask_range_batch(_t(depth, dev)[None, None], rat
 print("reliable-mask px differing product vs oracle:", int((rel_p != (rel[0, 0] > 0)).sum()))
 pts_p = renderer.unproject_points(_t(depth, dev)[None, None], torch.eye(4, device=dev)[None], _t(K, dev)[None])[0].cpu().numpy()
 print("unprojected points max abs diff:", float(np.abs(pts_p - pts[0]).max()))
+
+# ---- which path loses / changes a contribution? the same pair under every form of the renderer
+from gen3c_amd import _lib  # noqa: E402
+lib = _lib.load()
+
+
+def run(label, opts, window=True):
+    for k_, v_ in opts.items():
+        assert lib.g3_set_option(k_.encode(), v_) == 0
+    renderer._WINDOW_SPLAT = window
+    try:
+        c2 = renderer.Cache3D_Buffer(frame_buffer_max=2, noise_aug_strength=0, input_image=_t(img, dev)[None], input_depth=_t(depth, dev)[None, None],
+                                     input_w2c=torch.eye(4, device=dev)[None], input_intrinsics=_t(K, dev)[None], filter_points_threshold=0.05,
+                                     foreground_masking=False, input_format=["B", "C", "H", "W"])
+        p2, m2_ = c2.render_cache(_t(w2cs, dev)[None], _t(K, dev)[None, None].expand(1, 2, 3, 3))
+        torch.cuda.synchronize()
+        g2 = p2[0, :, 0].cpu().numpy()
+        e2 = np.abs(g2 - fr)
+        b2_ = e2 > (1e-4 + 1e-3 * np.abs(fr))
+        print(f"{label}: outliers {int(b2_.sum())} max {e2.max():.3e}; mask px differing {int((m2_[0, :, 0].cpu().numpy() != m2).sum())}; vs default product: "
+              f"{int((np.abs(g2 - got) > 1e-4 + 1e-3 * np.abs(got)).sum())} values differ")
+    finally:
+        renderer._WINDOW_SPLAT = True
+        for k_ in opts:
+            lib.g3_set_option(k_.encode(), {"render_fused": 1, "render_full_extent": 1, "render_exclusive": 0, "splat_tiled": 1, "render_overlap": 1}[k_])
+
+
+run("default", {})
+run("render_fused=0", {"render_fused": 0})
+run("render_full_extent=0", {"render_full_extent": 0})
+run("render_exclusive=1", {"render_exclusive": 1})
+run("two-call form (global accumulator atomics)", {}, window=False)
+run("two-call form, splat_tiled=0", {"splat_tiled": 0}, window=False)
+# the oracle with the product's fast-math depth weight (hardware log2 / exp2 / rcp: ~1e-5 relative) - does the weight's precision explain it?
+wsum64 = np.zeros((2, h + 2, w + 2), np.float64)
+csum64 = np.zeros((2, h + 2, w + 2, 3), np.float64)
+frc = np.moveaxis(np.broadcast_to(img[None], (2, 3, h, w)), 1, -1).astype(np.float64)
+for key, yy, xx in (("nw", "fy", "fx"), ("sw", "cy", "fx"), ("ne", "fy", "cx"), ("se", "cy", "cx")):
+    wt = (idx[key].astype(np.float64) * mask1[:, 0] / dw[:, 0].astype(np.float64))
+    np.add.at(wsum64, (bi, idx[yy], idx[xx]), wt)
+    np.add.at(csum64, (bi, idx[yy], idx[xx]), frc * wt[..., None])
+ref64 = np.moveaxis(csum64[:, 1:-1, 1:-1] / np.maximum(wsum64[:, 1:-1, 1:-1, None], 1e-300), -1, 1)
+e64 = np.abs(fr - ref64) * (m2 > 0)
+print("oracle fp32 vs the same sums in fp64: values beyond tolerance", int((e64 > 1e-4 + 1e-3 * np.abs(ref64)).sum()), "max", e64.max())
+e64g = np.abs(got - ref64) * (m2 > 0)
+print("product vs fp64 sums: values beyond tolerance", int((e64g > 1e-4 + 1e-3 * np.abs(ref64)).sum()), "max", e64g.max())
