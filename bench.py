@@ -988,7 +988,7 @@ def main():
                     cross_attention_ms_per_step=round(sum(ms for _, ms in tmz) / 2, 2) if tmz else None,
                     dense_cross_attention_ms_per_step=round(sum(dense_ca) / args.steps, 2) if dense_ca else None, output_finite=bool(torch.isfinite(xz.float()).all()),
                     note="NOT the headline: `value` times the dense workload (all 512 context tokens through the attention loop); this is the product default on the same "
-                         "zero-padded context (g3_flash_attn_fwd_ztail_bf16: same softmax, the all-zero K / V tail in closed form)")
+                         "zero-padded context (g3_cross_attn_fwd_bf16: same softmax, the all-zero K / V tail in closed form)")
             except Exception as e:
                 out["cross_attention_zero_tail"] = {"error": repr(e)}
             finally:

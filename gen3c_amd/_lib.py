@@ -35,8 +35,8 @@ SIGNATURES = {
     "g3_flash_attn_kernel_name": [i32, i32, i32, i32],
     "g3_flash_attn_fwd_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32,
                                i32, i32, f32, vp],
-    "g3_flash_attn_fwd_ztail_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32,
-                                     i32, f32, vp],
+    "g3_cross_attn_fwd_bf16": [vp, i64, i64, i64, vp, f32, vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i32, i32, i32, i32,
+                               i32, f32, vp],
     "g3_flash_attn_fwd_ex_bf16": [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64, i32, i64, vp, vp, vp, i64, i64, i64, i32, i32, i32,
                                   i32, i32, f32, i32, vp],
     "g3_flash_attn_kernel_name_ex": [i32, i32, i32, i32, i32],

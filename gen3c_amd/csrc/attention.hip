@@ -53,12 +53,17 @@ struct AttnParams {
     // softmax scale included); g3_attn_merge_partials_bf16 combines the parts of a row: softmax over the union of their keys.
     float* O32;
     float* LSE;
-    // zero-tail shortcut (v3 kernels; g3_flash_attn_fwd_ztail_bf16): 0 < kv_dense < Skv, a multiple of 64: the caller GUARANTEES that keys [kv_dense, Skv) have
+    // zero-tail shortcut (v3 kernels; g3_cross_attn_fwd_bf16): 0 < kv_dense < Skv, a multiple of 64: the caller GUARANTEES that keys [kv_dense, Skv) have
     // all-zero K rows AND all-zero V^T columns (zero-padded T5 tokens: to_k / to_v have no bias and RMSNorm(0) = 0). Their scores are exactly 0 and their values
     // add nothing, so only the first kv_dense keys go through the tile loop and the epilogue adds the tail in closed form: m' = max(m, 0),
     // l' = l 2^(m - m') + (Skv - kv_dense) 2^(-m'), O scaled by 2^(m - m') - the same softmax over all Skv keys (they stay in the denominator,
     // general_dit.py:407-410). 0 = every key goes through the loop.
     int kv_dense;
+    // per-head RMSNorm of Q inside the kernel's Q load (v3 kernels; g3_cross_attn_fwd_bf16): q_norm_w != nullptr -> every query row of a head is replaced by
+    // bf16(q * rsqrt(mean(q^2) + eps) * w) before it is used (te.pytorch.RMSNorm of Attention.to_q[1], attention.py:130-131, 262-273) - the cross-attention's Q
+    // then never makes the separate read + write pass of g3_qk_rmsnorm_rope_bf16.
+    const bf16_t* q_norm_w;
+    float q_norm_eps;
 };
 
 G3_DEVICE int k_off(int row, int chunk) { return row * HD + ((chunk ^ (row & 15)) << 3); }          // [64][128]
@@ -543,6 +548,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void flash_attn_fwd_v3_kernel(AttnPara
         const bf16_t* qrow = Qb + (int64_t)(q_ok ? q_idx : 0) * p.q_row + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = q_ok ? load_bf16x8(qrow + 16 * ks) : zero_bf16x8();
+        if (p.q_norm_w) {  // (wave-uniform) the row's 128 features sit in this lane's 64 elements + those of lane ^ 32
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)qf[ks][e]; ss += f * f; }
+            ss = xor32_sum(ss);
+            const float rinv = rsqrtf(ss * (1.0f / 128.0f) + p.q_norm_eps);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 w8 = load_bf16x8(p.q_norm_w + 16 * ks + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = f32_to_bf16((float)qf[ks][e] * rinv * (float)w8[e]);
+            }
+        }
         if (FOLD) {  // FOLD: the softmax scale (in the exp2 domain) rides on Q, the running maximum on the MFMA's C operand
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
@@ -956,7 +976,8 @@ extern "C" const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H) 
 static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
                              int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, int vt_seg_len,
                              int64_t vt_seg_stride, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int B, int H,
-                             int head_dim, float softmax_scale, void* stream, int variant_req = 0, float* o_partial = nullptr, float* lse = nullptr, int kv_dense = 0) {
+                             int head_dim, float softmax_scale, void* stream, int variant_req = 0, float* o_partial = nullptr, float* lse = nullptr, int kv_dense = 0,
+                             const void* q_norm_w = nullptr, float q_norm_eps = 0.f) {
     if (!q || !k || !vt || (!o && !o_partial)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_bf16: null operand");
     if ((o_partial != nullptr) != (lse != nullptr)) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: o_partial and lse go together");
     if (o_partial && (((uintptr_t)o_partial & 15) || ((uintptr_t)lse & 3))) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: misaligned o_partial / lse");
@@ -984,9 +1005,11 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     p.kv_dense = 0;
     if (kv_dense > 0) {
         const int kd = ((kv_dense + KVB - 1) / KVB) * KVB;  // whole tiles: the keys between kv_dense and the tile end are zero rows like the rest of the tail
-        if (kv_dense > Skv) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ztail_bf16: kv_dense %d > S_kv %d", kv_dense, Skv);
+        if (kv_dense > Skv) return g3_set_error(G3_ERR_ARG, "g3_cross_attn_fwd_bf16: kv_dense %d > S_kv %d", kv_dense, Skv);
         if (kd < Skv) p.kv_dense = kd;
     }
+    p.q_norm_w = (const bf16_t*)q_norm_w; p.q_norm_eps = q_norm_eps;
+    if (q_norm_w && ((uintptr_t)q_norm_w & 15)) return g3_set_error(G3_ERR_ARG, "g3_cross_attn_fwd_bf16: misaligned q_norm_weight");
     const size_t smem = (size_t)2 * (KVB * HD + HD * KVB) * sizeof(bf16_t);  // 64 KiB
     static bool attr_set[64] = {};  // per device: hipFuncSetAttribute applies to the current device only
     static std::mutex attr_mu;
@@ -995,7 +1018,7 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
     // 4 = 3 + folded scale/max on long contexts, 5-8 test forms of 4, 9 = w4 (one wave per SIMD), 10 = w4b, 11 = w4b + cross-barrier prefetch.
     int variant = attn_resolve_variant(Sq, Skv, B, H, variant_req);
     if (o_partial && variant == 9) variant = 4;  // w4 (ragged S_kv) has no partial epilogue: the 8-wave kernel takes ragged tiles too
-    if (p.kv_dense && (variant < 3 || variant >= 9)) variant = 4;  // the zero-tail epilogue lives in the v3 kernels
+    if ((p.kv_dense || p.q_norm_w) && (variant < 3 || variant >= 9)) variant = 4;  // the zero-tail epilogue and the Q norm live in the v3 kernels
     if (variant >= 3 && vt_row < ((kv_span + KVB - 1) / KVB) * KVB) variant = 2;  // (also 6-8)  // v3 reads the whole last V^T tile unguarded
     if (variant >= 3) {
         // v3 addresses its K / V^T LDS-DMA sources with 32-bit BYTE offsets from the per-(batch, head) base pointers: the largest
@@ -1085,14 +1108,14 @@ extern "C" int g3_flash_attn_fwd_kvseg_bf16(const void* q, int64_t q_row, int64_
                              o_batch, o_head, Sq, Skv, B, H, head_dim, softmax_scale, stream);
 }
 
-/* ---- zero-tail shortcut (AttnParams::kv_dense): the caller guarantees all-zero K rows and V^T columns for keys [kv_dense, Skv) ------------------------------- */
-extern "C" int g3_flash_attn_fwd_ztail_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row, int64_t k_batch,
-                                            int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, void* o, int64_t o_row,
-                                            int64_t o_batch, int64_t o_head, int Sq, int Skv, int kv_dense, int B, int H, int head_dim, float softmax_scale,
-                                            void* stream) {
-    if (kv_dense <= 0) return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ztail_bf16: kv_dense must be positive (all keys dense: g3_flash_attn_fwd_bf16)");
+/* ---- cross-attention form: optional per-head RMSNorm of Q in the kernel's Q load (AttnParams::q_norm_w) and optional all-zero key tail (AttnParams::kv_dense) ---- */
+extern "C" int g3_cross_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* q_norm_weight, float q_norm_eps, const void* k,
+                                      int64_t k_row, int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head, void* o,
+                                      int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int kv_dense, int B, int H, int head_dim,
+                                      float softmax_scale, void* stream) {
+    if (kv_dense < 0) return g3_set_error(G3_ERR_ARG, "g3_cross_attn_fwd_bf16: kv_dense must be >= 0 (0 = every key through the loop)");
     return flash_attn_launch(q, q_row, q_batch, q_head, k, k_row, k_batch, k_head, vt, vt_row, vt_batch, vt_head, 0, 0, o, o_row, o_batch, o_head, Sq, Skv, B, H,
-                             head_dim, softmax_scale, stream, 0, nullptr, nullptr, kv_dense);
+                             head_dim, softmax_scale, stream, 0, nullptr, nullptr, kv_dense, q_norm_weight, q_norm_eps);
 }
 
 /* ---- per-call kernel choice + split-KV partial outputs ------------------------------------------------------------------------------------ */

@@ -38,6 +38,12 @@ _FUSE_QKV_EPILOGUE = __import__("os").environ.get("G3_FUSE_QKV_EPILOGUE", "0") !
 _V_OPERAND_SWAP = __import__("os").environ.get("G3_V_OPERAND_SWAP", "1") != "0"
 
 
+# 1 (default, round 6): the cross-attention's Q goes from the projection GEMM straight into the attention kernel, which applies to_q[1]'s per-head RMSNorm while
+# it loads the rows (g3_cross_attn_fwd_bf16) - the separate norm pass (one read + one write of the [S*B, 4096] Q per block, ~10 ms of a 3.3 s step) is gone.
+# Same rounding points as the separate pass; the 128 squares are summed in another order (tests/test_kernels_gpu.py). 0: separate pass (A/B).
+_CROSS_Q_NORM_IN_ATTENTION = __import__("os").environ.get("G3_CROSS_Q_NORM_IN_ATTENTION", "1") != "0"
+
+
 def _project_norm_rope(h, w, n_q, n_k, norm_q, norm_k, cos, sin, S, B, nH_total):
     """a @ w^T with per-head RMSNorm (+ RoPE) on the first n_q (weight norm_q) and the next n_k (norm_k) output features; the rest plain.
     Same rounding points either way (tested): the fused GEMM epilogue, or the plain GEMM followed by the in-place norm passes."""
@@ -518,9 +524,12 @@ class VideoExtendGeneralDIT(nn.Module):
             # -- cross attention (unmasked over all M context tokens, general_dit.py:407-410)
             shift, scale, gate = self._modulation(emb, blk["ada"][1], adaln_lora, 3)
             h = ops.layernorm_modulate(xs, shift, scale)
-            q = _project_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B, nH)
             k, vt = ca_kv[bi]
-            o = ops.flash_attn(q, k, vt, S, M, B, nH, kv_dense=ca_dense)
+            if _CROSS_Q_NORM_IN_ATTENTION:  # plain projection; to_q[1]'s per-head RMSNorm runs in the attention kernel's Q load (no RoPE in cross-attention)
+                o = ops.flash_attn(ops.gemm_nt(h, blk["ca_q"]), k, vt, S, M, B, nH, kv_dense=ca_dense, q_norm_weight=blk["ca_qn"])
+            else:
+                q = _project_norm_rope(h, blk["ca_q"], D, 0, blk["ca_qn"], None, None, None, S, B, nH)
+                o = ops.flash_attn(q, k, vt, S, M, B, nH, kv_dense=ca_dense)
             ops.gemm_nt(o, blk["ca_out"], out=xs, epilogue=ops.EPI_GATED_RESIDUAL, gate=gate, residual=xs)
             # -- MLP
             shift, scale, gate = self._modulation(emb, blk["ada"][2], adaln_lora, 3)
@@ -570,7 +579,7 @@ class VideoExtendGeneralDIT(nn.Module):
         # Zero-padded context (text_encoder pads the T5 embedding with zero rows to 512 tokens): to_k / to_v have no bias and RMSNorm(0) = 0, so the padding's K
         # rows and V^T columns are exactly zero in every block. How many leading tokens carry anything is read ONCE per cached context (one host
         # synchronisation, with the K / V^T tails VERIFIED to be zero on the device) and handed to the attention launch, which then runs its tile loop over
-        # those keys only and adds the tail in closed form (g3_flash_attn_fwd_ztail_bf16: the padded tokens stay in the softmax denominator exactly as
+        # those keys only and adds the tail in closed form (g3_cross_attn_fwd_bf16: the padded tokens stay in the softmax denominator exactly as
         # general_dit.py:407-410 has them). A context without a zero tail, or any non-zero found in a tail, gives 0 = every key through the loop.
         dense = 0
         live = (crossattn_emb != 0).any(dim=-1).any(dim=0)  # [M]: token m is non-zero for some batch item

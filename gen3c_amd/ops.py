@@ -235,14 +235,16 @@ def transpose_v(v: torch.Tensor, S: int, B: int, H: int, out: Optional[torch.Ten
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv: int, B: int, H: int,
-               out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None, variant: int = 0, partial: bool = False, kv_dense: int = 0):
+               out: Optional[torch.Tensor] = None, softmax_scale: Optional[float] = None, variant: int = 0, partial: bool = False, kv_dense: int = 0,
+               q_norm_weight: Optional[torch.Tensor] = None, q_norm_eps: float = 1e-6):
     """q: [Sq*B, H*128], k: [Skv*B, H*128] (rows (s,b), b fastest), vt: [B, H, 128, ldvt] -> out [Sq*B, H*128].
     vt may also be 5-D [n_seg, B, H, 128, ld_seg]: V^T in key segments of Skv / n_seg keys each (a rank-major all-gather of
     per-rank V^T shards, see g3_flash_attn_fwd_kvseg_bf16).
     variant: per-call kernel choice (0 = library option / automatic; 4 = 8-wave kernel, 11 = one-wave-per-SIMD kernel) - no global state.
     partial=True: the keys are only PART of the rows' keys - returns (o_part fp32 [Sq*B, H*128], lse fp32 [B, H, Sq]) for attn_merge.
     kv_dense (0 < kv_dense < Skv): the CALLER guarantees all-zero K rows and V^T columns for keys [kv_dense, Skv) (zero-padded context tokens): they enter the
-    softmax in closed form instead of through the tile loop (g3_flash_attn_fwd_ztail_bf16)."""
+    softmax in closed form instead of through the tile loop; q_norm_weight ([128] bf16): q is the raw projection and its per-head RMSNorm runs inside the
+    kernel's Q load (both: g3_cross_attn_fwd_bf16)."""
     qr, qw, ldq = _rowmajor2d(q, "q")
     kr, kw, ldk = _rowmajor2d(k, "k")
     assert qr == Sq * B and kr == Skv * B and qw == H * 128 and kw == H * 128
@@ -268,14 +270,16 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Sq: int, Skv:
     n_seg = vt.shape[0] if vt.dim() == 5 else 0
     if n_seg:
         assert Skv % n_seg == 0
-    if 0 < kv_dense < Skv:
-        assert not partial and not n_seg and not variant, "the zero-tail form takes plain V^T, a bf16 output and the automatic kernel choice"
-        _lib.check(lib.g3_flash_attn_fwd_ztail_bf16(_dev(q, "q"), ldq * B, ldq, 128, _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,
-                                                    _dev(out, "out"), ldo * B, ldo, 128, Sq, Skv, int(kv_dense), B, H, 128, float(softmax_scale), _stream()),
-                   "g3_flash_attn_fwd_ztail_bf16")
+    if 0 < kv_dense < Skv or q_norm_weight is not None:
+        assert not partial and not n_seg and not variant, "the cross-attention form takes plain V^T, a bf16 output and the automatic kernel choice"
+        kd = int(kv_dense) if 0 < kv_dense < Skv else 0
+        _lib.check(lib.g3_cross_attn_fwd_bf16(_dev(q, "q"), ldq * B, ldq, 128, _dev(q_norm_weight, "q_norm_weight") if q_norm_weight is not None else 0, float(q_norm_eps),
+                                              _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,
+                                              _dev(out, "out"), ldo * B, ldo, 128, Sq, Skv, kd, B, H, 128, float(softmax_scale), _stream()),
+                   "g3_cross_attn_fwd_bf16")
         if timer is not None:
             timer.stop()
-            _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H, partial=False, kv_dense=int(kv_dense),
+            _KERNEL_TIMERS.append(("flash_attn_fwd", dict(Sq=Sq, Skv=Skv, B=B, H=H, partial=False, kv_dense=kd, q_norm=q_norm_weight is not None,
                                                           kernel=lib.g3_flash_attn_kernel_name_ex(Sq, Skv, B, H, 4).decode()), timer))
         return out
     _lib.check(lib.g3_flash_attn_fwd_ex_bf16(_dev(q, "q"), ldq * B, ldq, 128, _dev(k, "k"), ldk * B, ldk, 128, _dev(vt, "vt"), ldvt, H * 128 * ldvt, 128 * ldvt,

@@ -84,16 +84,19 @@ int g3_flash_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_
  * between the 8-wave and the one-wave-per-SIMD kernels): for profilers and bench.py's roofline line, never needed to run the op. */
 const char* g3_flash_attn_kernel_name(int Sq, int Skv, int B, int H);
 
-/* Same, for keys with an ALL-ZERO TAIL: the caller guarantees that the K rows AND the V^T columns of keys [kv_dense, S_kv) are exactly zero - the
- * cross-attention over a T5 context that text_encoder zero-pads to 512 tokens (to_k / to_v carry no bias and RMSNorm(0) = 0, so the padding stays zero
- * through Attention.cal_qkv, attention.py:247-280). Those keys score exactly 0 and add nothing to the output but they DO stay in the softmax denominator
- * (the reference attends over all 512 context tokens unmasked, general_dit.py:407-410): only the first ceil64(kv_dense) keys go through the kernel's
- * tile loop, the tail enters in closed form (m' = max(m, 0), l' = l 2^(m-m') + n_tail 2^(-m')). Same function of the same inputs; S_kv / ceil64(kv_dense)
- * times less matrix work. 0 < kv_dense <= S_kv. */
-int g3_flash_attn_fwd_ztail_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* k, int64_t k_row,
-                                 int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch, int64_t vt_head,
-                                 void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int kv_dense, int B, int H,
-                                 int head_dim, float softmax_scale, void* stream);
+/* The CROSS-attention form of the same call (Attention.forward with a context: cal_qkv's to_q[1] norm + DotProductAttention, attention.py:247-297), two options:
+ *  - q_norm_weight != NULL: q holds the RAW to_q[0] projection; the per-head te.pytorch.RMSNorm(128, eps) with this weight (attention.py:130-131, 262-273) is
+ *    applied inside the kernel's Q load, so the cross-attention's Q never makes the separate read + write pass of g3_qk_rmsnorm_rope_bf16 (no RoPE here:
+ *    cross-attention applies none). NULL: q is used as it is.
+ *  - kv_dense > 0: keys with an ALL-ZERO TAIL - the caller guarantees that the K rows AND the V^T columns of keys [kv_dense, S_kv) are exactly zero: a T5
+ *    context that text_encoder zero-pads to 512 tokens (to_k / to_v carry no bias and RMSNorm(0) = 0, so the padding stays zero through cal_qkv). Those keys
+ *    score exactly 0 and add nothing to the output but they DO stay in the softmax denominator (the reference attends over all 512 context tokens unmasked,
+ *    general_dit.py:407-410): only the first ceil64(kv_dense) keys go through the kernel's tile loop, the tail enters in closed form (m' = max(m, 0),
+ *    l' = l 2^(m-m') + n_tail 2^(-m')). Same function of the same inputs. 0: every key goes through the loop. */
+int g3_cross_attn_fwd_bf16(const void* q, int64_t q_row, int64_t q_batch, int64_t q_head, const void* q_norm_weight, float q_norm_eps,
+                           const void* k, int64_t k_row, int64_t k_batch, int64_t k_head, const void* vt, int64_t vt_row, int64_t vt_batch,
+                           int64_t vt_head, void* o, int64_t o_row, int64_t o_batch, int64_t o_head, int Sq, int Skv, int kv_dense, int B, int H,
+                           int head_dim, float softmax_scale, void* stream);
 
 /* Same, with V^T stored in KEY SEGMENTS: keys [s*vt_seg_len, (s+1)*vt_seg_len) live in the block at vt + s*vt_seg_stride (each block
  * laid out as above with its own vt_row >= vt_seg_len). vt_seg_len must be a multiple of 64 and divide S_kv. This is what a rank-major

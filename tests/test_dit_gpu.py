@@ -150,7 +150,7 @@ def test_cross_attention_kv_cache_follows_context_and_weights():
 
 def test_cross_attention_zero_padded_context_shortcut_matches_dense():
     """Round 6: a context whose tokens beyond the prompt are zero rows (how text_encoder pads T5 embeddings to 512) is detected once per cached context
-    and the cross-attention then loops over the live keys only (g3_flash_attn_fwd_ztail_bf16) - the forward must equal the one with the shortcut switched
+    and the cross-attention then loops over the live keys only (g3_cross_attn_fwd_bf16) - the forward must equal the one with the shortcut switched
     off (every key through the loop) up to the summation order of the identical tail terms; a context WITHOUT a zero tail must not take the shortcut."""
     from gen3c_amd.dit import VideoExtendGeneralDIT
     dev = torch.device("cuda:0")

