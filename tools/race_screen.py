@@ -75,6 +75,29 @@ for (Sq, Skv, H, segs) in [(56320, 56320, 4, 1), (7040, 56320, 4, 8), (1000, 449
         report(f"attention Sq={Sq} Skv={Skv} H={H} segs={segs} variant={variant}", a, b)
     del q, k, v, vt
 
+# ---- cross-attention form (round 6): Q norm inside the Q load + zero key tail in closed form
+for (Sq, Skv, H, live) in [(56320, 512, 8, 64), (1000, 512, 3, 0), (3000, 256, 2, 100)]:
+    q = torch.randn(Sq, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(Skv, H * 128, device=dev, generator=g).to(torch.bfloat16)
+    if live:
+        k[live:] = 0
+        v[live:] = 0
+    wq = (torch.rand(128, device=dev, generator=g) + 0.5).to(torch.bfloat16)
+    vt = ops.transpose_v(v, Skv, 1, H)
+    ld = vt.shape[-1]
+
+    def run(lib):
+        lib.g3_set_option(b"attn_variant", 0)
+        o = torch.empty_like(q)
+        rc = lib.g3_cross_attn_fwd_bf16(q.data_ptr(), H * 128, H * 128, 128, wq.data_ptr(), 1e-6, k.data_ptr(), H * 128, H * 128, 128, vt.data_ptr(), ld, H * 128 * ld, 128 * ld,
+                                        o.data_ptr(), H * 128, H * 128, 128, Sq, Skv, live, 1, H, 128, 1.0 / math.sqrt(128), st)
+        assert rc == 0, lib.g3_last_error()
+        return o
+    a, b = both(run)
+    report(f"cross-attention form Sq={Sq} Skv={Skv} H={H} live={live} (q norm in the kernel)", a, b)
+    del q, k, v, vt
+
 # ---- GEMM: every K-loop structure x epilogues x ragged shapes
 for (M, N, K, epi) in [(56320, 4096, 4096, 2), (7040, 12288, 4096, 0), (4096, 16384, 4096, 1), (3000, 4096, 16384, 2), (513, 264, 192, 3), (300, 520, 128, 0),
                        (256, 256, 64, 0), (8192, 12288, 4096, 0), (16384, 16384, 4096, 1), (8448, 4096, 2432, 2)]:
