@@ -229,19 +229,22 @@ def _pmc_pass(counter: str, probe: str, extra_env: dict, timeout_s: int):
 
 def measure_render_traffic(timeout_s: int = 150):
     """`roofline_render.traffic` measured in this run: FETCH_SIZE and WRITE_SIZE passes over tools/bench_render_single.py restricted to the benchmarked configuration
-    (foreground masking; 4 renders x 32 items in the child process), summed over every renderer kernel (warp_* / mesh_*) and divided by the 128 items. Raw counters, no
-    correction factor: the renderer's loads are 4 B/lane, for which the guide gives no calibration (profiles/r3_render_traffic.json found FETCH_SIZE ~0.83x there)."""
+    (foreground masking; 4 renders x 32 items in the child process), summed over every renderer kernel (warp_* / mesh_*) and divided by the 128 items.
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: calibrated in round 6 on this pool against product kernels of known traffic (tools/pmc_calibrate.py,
+    profiles/r6_pmc_calibration.txt): the counters are in KiB, WRITE_SIZE is exact, and FETCH_SIZE tallies HALF the bytes not only of 16 B/lane streams (the guide's
+    gfx950 note) but also of coalesced 4 B/lane loads - the renderer's two load forms. Rounds 3-5 quoted the raw sum x 1000 (`traffic_raw_r5_convention`)."""
     try:
-        tot = 0.0
         parts = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             kb = sum_pmc_csv(_pmc_pass(counter, "bench_render_single.py", {"G3_RENDER_ONLY_FG": "1"}, timeout_s), ("warp_", "mesh_"), counter)
             if kb <= 0:
                 return None, f"no renderer dispatch in the {counter} pass"
             parts[counter] = kb
-            tot += kb * 1000.0
+        tot = (2.0 * parts["FETCH_SIZE"] + parts["WRITE_SIZE"]) * 1024.0
         return int(tot / 128), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/bench_render_single.py (foreground masking, 4 x 32 items "
-                                f"in a child process), all warp_* / mesh_* kernels, per item; raw counters (FETCH_SIZE {parts['FETCH_SIZE']:.4g} KB + WRITE_SIZE {parts['WRITE_SIZE']:.4g} KB) / 128")
+                                f"in a child process), all warp_* / mesh_* kernels, per item; (2 x FETCH_SIZE {parts['FETCH_SIZE']:.4g} KiB + WRITE_SIZE {parts['WRITE_SIZE']:.4g} KiB) x 1024 / 128 "
+                                f"[profiles/r6_pmc_calibration.txt: FETCH_SIZE counts half the bytes of coalesced 4 B and 16 B per-lane loads on gfx950; the raw sum x 1000 of rounds 3-5 would read "
+                                f"{int((parts['FETCH_SIZE'] + parts['WRITE_SIZE']) * 1000.0 / 128)}]")
     except Exception as e:  # noqa: BLE001
         return None, repr(e)
 
@@ -249,8 +252,9 @@ def measure_render_traffic(timeout_s: int = 150):
 def measure_attention_traffic(kernel_substr: str = "flash_attn_fwd_w4b", timeout_s: int = 150):
     """`roofline.traffic` measured IN THIS RUN: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: one counter per
     pass, nothing else, as MI355X_MICROARCH.md's HBM section prescribes) over tools/pmc_probe.py, which issues the benchmark's own self-attention launch
-    (S = 56 320, H = 32, B = 2, strided q / k views) twice in a child process on this box, from /tmp. bytes = FETCH_SIZE[KB] x 1000 x 2 (the guide's gfx950
-    correction: 16 B/lane coalesced reads are tallied at half size) + WRITE_SIZE[KB] x 1000. Returns (bytes per launch, description) or (None, why)."""
+    (S = 56 320, H = 32, B = 2, strided q / k views) twice in a child process on this box, from /tmp. bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the guide's gfx950
+    correction: 16 B/lane coalesced reads are tallied at half size; counters in KiB - both confirmed on known byte counts, profiles/r6_pmc_calibration.txt).
+    Returns (bytes per launch, description) or (None, why)."""
     import shutil
     import subprocess
     import tempfile
@@ -275,9 +279,9 @@ def measure_attention_traffic(kernel_substr: str = "flash_attn_fwd_w4b", timeout
             return None, f"rocprofv3 --pmc {counter}: {e!r}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    total = int(got["FETCH_SIZE"] * 1000 * 2 + got["WRITE_SIZE"] * 1000)
+    total = int((got["FETCH_SIZE"] * 2 + got["WRITE_SIZE"]) * 1024)
     return total, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_probe.py = this launch in a child process; "
-                   f"FETCH_SIZE {got['FETCH_SIZE']:.4g} KB x 2 (gfx950 correction of the guide) + WRITE_SIZE {got['WRITE_SIZE']:.4g} KB")
+                   f"(FETCH_SIZE {got['FETCH_SIZE']:.4g} KiB x 2 (gfx950 correction of the guide) + WRITE_SIZE {got['WRITE_SIZE']:.4g} KiB) x 1024")
 
 
 TOK_FIXTURE = ROOT / "tests" / "golden" / "tokenizer_fullsize_samples.npz"
@@ -368,7 +372,7 @@ def stage_rooflines(dev):
     gbs = 43.2e6 / (per_item * 1e-3) / 1e9
     traffic = traffic_source = None  # memory-side bytes per item: QUOTED from the committed rocprofv3 PMC passes of this configuration
     try:
-        tf = next(f for f in ("r5_render_traffic.json", "r4_render_traffic.json", "r3_render_traffic.json") if (ROOT / "profiles" / f).exists())  # the latest committed PMC passes
+        tf = next(f for f in ("r6_render_traffic.json", "r5_render_traffic.json", "r4_render_traffic.json", "r3_render_traffic.json") if (ROOT / "profiles" / f).exists())  # the latest committed PMC passes
         tj = json.loads((ROOT / "profiles" / tf).read_text())
         traffic, traffic_source = tj["traffic_bytes_per_item"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, per item); not re-measured in this run"
     except Exception:
