@@ -1038,6 +1038,9 @@ static int flash_attn_launch(const void* q, int64_t q_row, int64_t q_batch, int6
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_kvseg_bf16: segmented V^T is implemented by the default (v3) kernel only");
     if (o_partial && variant < 3)
         return g3_set_error(G3_ERR_ARG, "g3_flash_attn_fwd_ex_bf16: split-KV partial outputs are implemented by the v3 / w4b kernels only (variant %d chosen)", variant);
+    if ((p.kv_dense || p.q_norm_w) && variant < 3)  // (a V^T leading dimension or an operand span that forced the 64-bit-addressing kernel above)
+        return g3_set_error(G3_ERR_ARG, "g3_cross_attn_fwd_bf16: the Q norm / zero-tail form is implemented by the v3 kernels only (variant %d chosen: V^T leading dimension below "
+                                        "ceil64(S_kv), or operands beyond the kernel's 32-bit byte offsets)", variant);
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return g3_set_error(G3_ERR_LAUNCH, "flash_attn: hipGetDevice failed");
     {

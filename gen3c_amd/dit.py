@@ -33,7 +33,7 @@ _FUSE_QKV_EPILOGUE = __import__("os").environ.get("G3_FUSE_QKV_EPILOGUE", "0") !
 
 # 1 (default, round 6): the V third of the self-attention QKV projection is computed with the operands SWAPPED - V^T[b] = W_v . h[:, b]^T, one GEMM per batch item whose
 # "token" operand is the weight and whose output rows are the 128 H value features - so it lands directly in the V^T [B, H, 128, S] layout the attention kernel reads and
-# the separate transpose pass (g3_transpose_v_bf16: 10.7 ms of a 3.3 s step at 2.4 TB/s) disappears. Same products, same K order per element: bitwise equal to the
+# the separate transpose pass (g3_transpose_v_bf16: 10.7 ms of a 3.3 s step) disappears. Same products, same K order per element: bitwise equal to the
 # transpose of the fused projection's v columns (tests/test_kernels_gpu.py). 0: fused [S*B, 3D] projection + transpose (A/B).
 _V_OPERAND_SWAP = __import__("os").environ.get("G3_V_OPERAND_SWAP", "1") != "0"
 
