@@ -173,6 +173,7 @@ def main():
     configs = [(int(c.split(",")[0]), c.split(",")[1], c.split(",")[2]) for c in args.configs.split(";")]
     net = VideoExtendGeneralDIT(in_channels=16 + 16 * 4 + 1, rope_t_extrapolation_ratio=2.0, num_blocks=args.blocks, device=dev, init_weights=False)
     net.initialize_weights(randomize_adaln=True, seed=1234)
+    net.cross_attention_skip_zero_context = False  # the dense workload bench.py times (the record profiles/r6_cp_rank_shapes.* was taken with the product default, ~17 / cp ms less per step)
     allres = []
     for cp in [int(c) for c in args.cps.split(",")]:
         rank = (cp // 2 if args.rank < 0 else args.rank) if cp > 1 else 0
