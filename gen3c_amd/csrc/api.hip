@@ -44,6 +44,7 @@ int g3_opt_gemm_deferred = env_int("G3_GEMM_DEFERRED", 1);  // block GEMMs with 
 int g3_opt_gemm_deferred_grid = env_int("G3_GEMM_DEFERRED_GRID", 0);  // tests: workgroup count of the deferred-epilogue GEMM (0 = one per CU)
 int g3_opt_gemm_tokens_first = env_int("G3_GEMM_TOKENS_FIRST", 2);  // gemm_w4e.hpp piece order: 0 weights first, 1 tokens first, 2 (default) tokens first where N <= 4096
 int g3_opt_conv_w4 = env_int("G3_CONV_W4", 1);  // tokenizer convolutions on the one-wave-per-SIMD kernel (gemm_w4_conv.hpp) where it applies
+int g3_opt_ln_wave_rows = env_int("G3_LN_WAVE_ROWS", 0);  // norm_rope.hip: ln_modulate_wave_kernel (A/B: profiles/r6_ln_wave_ab.txt)
 int g3_opt_norm_octets = env_int("G3_NORM_OCTETS", 1);  // norm_rope.hip: octet form of the per-head RMSNorm + RoPE pass (0: one group per (row, head), A/B)
 int g3_opt_gemm_unpinned = env_int("G3_GEMM_UNPINNED", 1);  // measured: pinning the LDS prefetch does not help this kernel (profiles/r1_v4_gemm_pin_ab.txt)
 
@@ -65,6 +66,7 @@ extern "C" int g3_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_deferred_grid")) { g3_opt_gemm_deferred_grid = value; return G3_OK; }
     if (!strcmp(name, "tok_tattn_px")) { g3_opt_tok_tattn_px = value; return G3_OK; }
     if (!strcmp(name, "gemm_rowmajor_tiles")) { g3_opt_gemm_rowmajor_tiles = value; return G3_OK; }
+    if (!strcmp(name, "ln_wave_rows")) { g3_opt_ln_wave_rows = value; return G3_OK; }
     if (!strcmp(name, "norm_octets")) { g3_opt_norm_octets = value; return G3_OK; }
     if (!strcmp(name, "attn_variant")) { g3_opt_attn_variant = value; return G3_OK; }
     if (!strcmp(name, "attn_xcd_heads")) { g3_opt_attn_xcd_heads = value; return G3_OK; }

@@ -44,6 +44,7 @@ extern int g3_opt_render_fused;         // 1 (default): g3_render_items_f32 proj
 extern int g3_opt_render_overlap;       // 1 (default): g3_render_items_f32 runs the occlusion pass on a side stream next to project + splat
 extern int g3_opt_splat_tiled;          // 1 (default): LDS-windowed splat; 0: direct global atomics (A/B)
 extern int g3_opt_attn_xcd_heads;  // 1 (default): w4b attention launches a 1-D grid and gives every XCD its own (batch, head) pairs
+extern int g3_opt_ln_wave_rows;        // 1: LayerNorm + AdaLN at D = 4096 with one wave per row (no LDS round trip / barrier); 0: one workgroup per row
 extern int g3_opt_norm_octets;         // 1 (default): per-head RMSNorm + RoPE in the octet form (one 8-lane group keeps a row's cos / sin for 8 heads) where H % 8 == 0
 extern int g3_opt_attn_variant;   // 1 non-pipelined, 2 software-pipelined, 3 LDS-DMA + pinned interleave, 4 (default) = 3 with the softmax scale folded into Q and the running max into the MFMA's C operand
 

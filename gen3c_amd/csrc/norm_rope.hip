@@ -126,6 +126,60 @@ __global__ __launch_bounds__(LN_THREADS) void ln_modulate_kernel(bf16_t* __restr
     }
 }
 
+// One WAVE per row (round 6; D = 4096 exactly: 8 chunks of 8 per lane), four rows per workgroup: the row never leaves the wave's registers, the two reductions are
+// six cross-lane steps each - no LDS round trip, no workgroup barrier (the form above pays two per row). Same two-pass arithmetic (mean, then the centred squares);
+// the partial sums are formed per lane over 64 elements instead of per thread over 16, so mean / variance can differ in the last fp32 bit. POS 0 / 2 as above.
+template <int POS>
+__global__ __launch_bounds__(256) void ln_modulate_wave_kernel(bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale,
+                                                               int64_t ldmod, int mod_rows, bf16_t* __restrict__ out, int64_t ldo, int rows, float eps, PosEmbArgs pe) {
+    constexpr int D = 4096;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t* pt = POS == 2 ? pe.pe_t + (int64_t)(row / pe.B) * D : nullptr;
+    float v[8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = lane + 64 * c;
+        bf16x8 t = load_bf16x8(xr + ch * 8);
+        if (POS == 2) {
+            const bf16x8 em = load_bf16x8(pt + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = f32_to_bf16((float)t[e] + (float)em[e]);
+            store_bf16x8(xr + ch * 8, t);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)D + eps);
+    const int mrow = row % mod_rows;
+    const bf16_t* sh = shift + (int64_t)mrow * ldmod;
+    const bf16_t* sc = scale + (int64_t)mrow * ldmod;
+    bf16_t* orow = out + (int64_t)row * ldo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = lane + 64 * c;
+        const bf16x8 tsh = load_bf16x8(sh + ch * 8);
+        const bf16x8 tsc = load_bf16x8(sc + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16((v[c][e] - mean) * rstd * (1.0f + (float)tsc[e]) + (float)tsh[e]);
+        store_bf16x8(orow + ch * 8, o);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // Per-head RMSNorm (learned weight, eps 1e-6, fp32 math) followed by non-interleaved RoPE.
 // Reference: Attention.cal_qkv (cosmos_predict1/diffusion/module/attention.py:262-280): to_q[1]/to_k[1] are
@@ -382,8 +436,12 @@ extern "C" int g3_layernorm_modulate_bf16(const void* x, int64_t ldx, const void
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: D=%d must be a multiple of 8 and <= %d", D, LN_THREADS * 8 * LN_MAX_CHUNKS);
     if ((ldx & 7) || (ldo & 7) || (ldmod & 7) || mod_rows <= 0)
         return g3_set_error(G3_ERR_ARG, "g3_layernorm_modulate_bf16: leading dims must be multiples of 8");
-    hipLaunchKernelGGL(ln_modulate_kernel<0>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
-                       (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, PosEmbArgs{});
+    if (D == 4096 && g3_opt_ln_wave_rows)
+        hipLaunchKernelGGL(ln_modulate_wave_kernel<0>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
+                           (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, eps, PosEmbArgs{});
+    else
+        hipLaunchKernelGGL(ln_modulate_kernel<0>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)const_cast<void*>(x), ldx,
+                           (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, PosEmbArgs{});
     return g3_check_launch("g3_layernorm_modulate_bf16");
 }
 
@@ -402,7 +460,10 @@ extern "C" int g3_posemb_layernorm_modulate_bf16(void* x, int64_t ldx, const voi
     if (rows64 > 0x7fffffff) return g3_set_error(G3_ERR_ARG, "g3_posemb_layernorm_modulate_bf16: too many rows");
     const int rows = (int)rows64;
     PosEmbArgs pe{(const bf16_t*)pe_t, (const bf16_t*)pe_h, (const bf16_t*)pe_w, (const bf16_t*)pos_norm, Hp, Wp, B};
-    if (materialised)
+    if (materialised && D == 4096 && g3_opt_ln_wave_rows)
+        hipLaunchKernelGGL(ln_modulate_wave_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, (const bf16_t*)shift, (const bf16_t*)scale,
+                           ldmod, mod_rows, (bf16_t*)out, ldo, rows, eps, pe);
+    else if (materialised)
         hipLaunchKernelGGL(ln_modulate_kernel<2>, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
                            (const bf16_t*)shift, (const bf16_t*)scale, ldmod, mod_rows, (bf16_t*)out, ldo, rows, D, eps, pe);
     else
