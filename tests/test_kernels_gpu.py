@@ -725,6 +725,15 @@ def test_hip_dot_product_attention_operator_seam():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("M,N,K,epi,gate_rows", [(14080, 4096, 4096, 2, 2), (14080, 4096, 4096, 0, 1), (14080, 4096, 16384, 2, 2), (14080, 12288, 4096, 0, 1),
+                                                 (14080, 16384, 4096, 1, 1), (28160, 4096, 4096, 2, 2), (28160, 4096, 16384, 2, 2)])
+def test_gemm_deferred_epilogue_kernel_at_the_context_parallel_rank_shapes(M, N, K, epi, gate_rows):
+    """the block GEMMs at ONE RANK's shapes under context parallelism - M = 2 x 7 040 (cp = 8: 55 x 16 = 880 tiles on 256 persistent workgroups,
+    3.44 rounds: 112 workgroups walk four tiles, 144 three) and M = 2 x 14 080 (cp = 4) - deferred-epilogue kernel BITWISE equal to the non-persistent one-wave
+    kernel, both piece orders, and within the fp32 bar on sampled rows (same body as test_gemm_deferred_epilogue_kernel)."""
+    test_gemm_deferred_epilogue_kernel(M, N, K, epi, gate_rows)
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 4096, 2432), (8448, 4096, 4096), (33792, 2048, 2560)])
 @pytest.mark.parametrize("epi,gate_rows", [(0, 1), (1, 1), (2, 1), (2, 2), (2, 4)])
 def test_gemm_deferred_epilogue_kernel(M, N, K, epi, gate_rows):
